@@ -1,0 +1,209 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * CPU oracle for the selective-frame k-means of StreamChat
+ * (reference: utiles.py:291-330 `weighted_kmeans_feature` / inner `weighted_kmeans_torch`
+ * :294-318).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call
+ * this.  Pinned against the golden vectors tests/golden/kmeans_*.npz, which were produced by
+ * running the reference's own function (tools/make_golden.py).
+ *
+ * Semantics restated (fp32-canonical, SURVEY.md §0 surprise 4: the reference overflows in fp16):
+ *   C_0 = X[init_idx]                                               utiles.py:295-296
+ *   loop i < max_iter:
+ *     labels_i[t] = argmin_k ||X[t]-C_i[k]||   (first minimum)      :299-302
+ *     S[k] = sum_{t:label=k} w_t X[t] ; W[k] = sum w_t              :303-308
+ *     C'[k] = S[k]/W[k] if W[k]>0 else X[reseed.pop()]              :309-313
+ *     if sum_k ||C_i[k]-C'[k]||_2 < tol: break  (C_i, labels_i kept) :314-316
+ *     C_{i+1} = C'                                                  :317
+ *   return C, labels, W, i        (on exhaustion C is one update ahead of labels — Q3)
+ *
+ * Reduction spec "SC-KM1" (shared, bit for bit, with streamchat_amd/csrc/kmeans.hip so that
+ * labels are identical by construction, ties included):
+ *   - columns are cut into chunks of 512 = 64 lanes x 8 elements; lane l of chunk c owns columns
+ *     c*512 + l*8 + e, e<8; columns >= D contribute 0.
+ *   - lane partial: d = x - c (fp32); even e feed acc0 = fmaf(d,d,acc0), odd e feed acc1;
+ *     p = acc0 + acc1.
+ *   - wave partial: for h in 32,16,8,4,2,1: p[a] += p[a+h] (a<h), fp32.
+ *   - total: chunks are cut into 32 contiguous segments of ceil(nchunks/32); each segment is summed
+ *     in ascending chunk order in fp64, then the 32 segment sums are summed in ascending order.
+ *   - argmin on the fp64 totals (sqrt is monotone; first minimum wins).
+ *   - update: per column, s = 0; for t in cluster (ascending): s = s + (w_t * x) in fp32 without
+ *     fma contraction; C' = s / W (fp32 division).  W likewise sequential fp32.
+ *   - shift: the same lane/wave/segment tree on (C_i - C')^2 per cluster, then
+ *     sum_k sqrt(total_k) in fp64, compared with (double)tol.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC kmeans_oracle.c -o libsc_oracle.so -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CH 512
+#define NSEG 32
+
+static inline float h2f(uint16_t h) { /* IEEE binary16 -> binary32, exact */
+    uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu, o;
+    if (e == 0) {
+        if (m == 0) o = s;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } m &= 0x3ffu; o = s | ((uint32_t)(113 - sh) << 23) | (m << 13); }
+    } else if (e == 31) o = s | 0x7f800000u | (m << 13);
+    else o = s | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &o, 4); return f;
+}
+static inline float b2f(uint16_t b) { uint32_t o = (uint32_t)b << 16; float f; memcpy(&f, &o, 4); return f; }
+
+/* dtype: 0 = f16, 1 = bf16, 2 = f32 */
+static inline float ldx(const void *X, int dtype, size_t i) {
+    if (dtype == 2) return ((const float *)X)[i];
+    uint16_t v = ((const uint16_t *)X)[i];
+    return dtype == 0 ? h2f(v) : b2f(v);
+}
+
+static float wave_tree(float *p) {
+    for (int h = 32; h >= 1; h >>= 1)
+        for (int a = 0; a < h; ++a) p[a] = p[a] + p[a + h];
+    return p[0];
+}
+
+/* fp32 wave partial of sum_j (a_j - b_j)^2 over chunk c; a/b fetched by callbacks on column index */
+static float chunk_partial_xc(const void *X, int dtype, size_t rowoff, const float *Crow, int64_t D, int64_t c) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            int64_t col = c * CH + l * 8 + e;
+            float x = 0.f, cc = 0.f;
+            if (col < D) { x = ldx(X, dtype, rowoff + (size_t)col); cc = Crow[col]; }
+            float d = x - cc;
+            if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+        }
+        p[l] = a0 + a1;
+    }
+    return wave_tree(p);
+}
+static float chunk_partial_cc(const float *A, const float *B, int64_t D, int64_t c) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            int64_t col = c * CH + l * 8 + e;
+            float d = 0.f;
+            if (col < D) d = A[col] - B[col];
+            if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+        }
+        p[l] = a0 + a1;
+    }
+    return wave_tree(p);
+}
+
+static double seg_total(const float *wp, int64_t nch) { /* wp[nch] fp32 chunk partials -> fp64 two-level sum */
+    int64_t seglen = (nch + NSEG - 1) / NSEG;
+    double tot = 0.0;
+    for (int s = 0; s < NSEG; ++s) {
+        double a = 0.0;
+        int64_t lo = (int64_t)s * seglen, hi = lo + seglen; if (hi > nch) hi = nch;
+        for (int64_t c = lo; c < hi; ++c) a += (double)wp[c];
+        tot += a;
+    }
+    return tot;
+}
+
+/* squared distances dist2[T*K] (fp64) of every row to every centroid, SC-KM1 order */
+void sc_oracle_kmeans_dist2(const void *X, int dtype, int T, int64_t D, int K, const float *C, double *dist2) {
+    int64_t nch = (D + CH - 1) / CH;
+#pragma omp parallel
+    {
+        float *wp = (float *)malloc(sizeof(float) * (size_t)nch);
+#pragma omp for schedule(dynamic, 1) collapse(2)
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < K; ++k) {
+                for (int64_t c = 0; c < nch; ++c)
+                    wp[c] = chunk_partial_xc(X, dtype, (size_t)t * (size_t)D, C + (size_t)k * D, D, c);
+                dist2[(size_t)t * K + k] = seg_total(wp, nch);
+            }
+        free(wp);
+    }
+}
+
+/* Full fit.  trace_labels (may be NULL): [max_iter*T] int32, row i = labels of iteration i.
+ * returns 0, or -1 on bad arguments.  reseed_idx may be NULL only if no cluster ever empties
+ * (returns -2 otherwise). */
+int sc_oracle_kmeans_fit(const void *X, int dtype, int T, int64_t D, int K, const float *w,
+                         const int32_t *init_idx, const int32_t *reseed_idx, int n_reseed, int max_iter, float tol,
+                         float *C /*[K*D] out*/, int64_t *labels /*[T] out*/, float *wsum /*[K] out*/, int *iters,
+                         int32_t *trace_labels) {
+    if (T <= 0 || D <= 0 || K <= 0 || max_iter <= 0) return -1;
+    int64_t nch = (D + CH - 1) / CH;
+    float *Ccur = (float *)malloc(sizeof(float) * (size_t)K * D), *Cnew = (float *)malloc(sizeof(float) * (size_t)K * D);
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)T * K);
+    float *wp = (float *)malloc(sizeof(float) * (size_t)nch);
+    int rpos = 0, rc = 0, i;
+    for (int k = 0; k < K; ++k) {
+        if (init_idx[k] < 0 || init_idx[k] >= T) { rc = -1; goto out; }
+        for (int64_t j = 0; j < D; ++j) Ccur[(size_t)k * D + j] = ldx(X, dtype, (size_t)init_idx[k] * D + j);
+    }
+    for (i = 0; i < max_iter; ++i) {
+        sc_oracle_kmeans_dist2(X, dtype, T, D, K, Ccur, d2);
+        for (int t = 0; t < T; ++t) {
+            int best = 0; double bv = d2[(size_t)t * K];
+            for (int k = 1; k < K; ++k) if (d2[(size_t)t * K + k] < bv) { bv = d2[(size_t)t * K + k]; best = k; }
+            labels[t] = best;
+            if (trace_labels) trace_labels[(size_t)i * T + t] = best;
+        }
+        for (int k = 0; k < K; ++k) {
+            float W = 0.f;
+            for (int t = 0; t < T; ++t) if (labels[t] == k) W = W + (w ? w[t] : 1.0f);
+            wsum[k] = W;
+            float *cn = Cnew + (size_t)k * D;
+            if (W > 0.f) {
+#pragma omp parallel for schedule(static)
+                for (int64_t j = 0; j < D; ++j) {
+                    float s = 0.f;
+                    for (int t = 0; t < T; ++t) if (labels[t] == k) {
+                        float prod = (w ? w[t] : 1.0f) * ldx(X, dtype, (size_t)t * D + j);
+                        s = s + prod;
+                    }
+                    cn[j] = s / W;
+                }
+            } else {
+                if (!reseed_idx || rpos >= n_reseed) { rc = -2; goto out; }
+                int r = reseed_idx[rpos++];
+                if (r < 0 || r >= T) { rc = -1; goto out; }
+                for (int64_t j = 0; j < D; ++j) cn[j] = ldx(X, dtype, (size_t)r * D + j);
+            }
+        }
+        double diff = 0.0;
+        for (int k = 0; k < K; ++k) {
+            for (int64_t c = 0; c < nch; ++c) wp[c] = chunk_partial_cc(Ccur + (size_t)k * D, Cnew + (size_t)k * D, D, c);
+            diff += sqrt(seg_total(wp, nch));
+        }
+        if (diff < (double)tol) break;
+        float *tmp = Ccur; Ccur = Cnew; Cnew = tmp;
+    }
+    if (i == max_iter) i = max_iter - 1;   /* python: loop variable after exhaustion */
+    *iters = i;
+    memcpy(C, Ccur, sizeof(float) * (size_t)K * D);
+out:
+    free(Ccur); free(Cnew); free(d2); free(wp);
+    return rc;
+}
+
+/* ---- retrieval oracle: cosine / flat-L2 top-k (utiles.py:732-740; local_doc_qa.py:270 FAISS flat L2) ----
+ * metric 0: cosine, scores descending; metric 1: squared L2, ascending.  fp64 accumulate in index
+ * order; ties -> lowest index.  idx/score sized k. */
+void sc_oracle_topk(const float *q, const float *docs, int M, int d, int k, int metric, int32_t *idx, float *score) {
+    double *s = (double *)malloc(sizeof(double) * (size_t)M);
+    double qn = 0; for (int j = 0; j < d; ++j) qn += (double)q[j] * q[j];
+    for (int m = 0; m < M; ++m) {
+        const float *x = docs + (size_t)m * d; double dot = 0, xn = 0, l2 = 0;
+        for (int j = 0; j < d; ++j) { dot += (double)q[j] * x[j]; xn += (double)x[j] * x[j]; double e = (double)q[j] - x[j]; l2 += e * e; }
+        s[m] = metric == 0 ? dot / (fmax(sqrt(qn), 1e-12) * fmax(sqrt(xn), 1e-12)) : l2;
+    }
+    char *used = (char *)calloc((size_t)M, 1);
+    for (int r = 0; r < k && r < M; ++r) {
+        int best = -1;
+        for (int m = 0; m < M; ++m) { if (used[m]) continue; if (best < 0 || (metric == 0 ? s[m] > s[best] : s[m] < s[best])) best = m; }
+        used[best] = 1; idx[r] = best; score[r] = (float)s[best];
+    }
+    free(used); free(s);
+}
