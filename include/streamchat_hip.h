@@ -1,0 +1,123 @@
+/* streamchat_hip.h — C ABI of libstreamchat_hip.so (hand-written gfx950 / CDNA4 kernels).
+ *
+ * The reference (hmxiong/StreamChat) is pure Python with NO plugin / FFI boundary
+ * (SURVEY.md §2.2, §8(b)); the seams it exposes are Python call signatures.  This header is the
+ * drop-in boundary the build defines underneath those seams: each entry point names the reference
+ * call site(s) whose arithmetic it replaces.  The Python host mirror (the streamchat_amd Python package) binds
+ * these symbols with ctypes on `tensor.data_ptr()`; INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / HIP C++ types in signatures
+ *     (`sc_stream_t` is a `hipStream_t` passed as void*; NULL = the default stream).
+ *   - return 0 on success, negative on error; `sc_last_error()` gives the text (thread-local).
+ *     Never throws or aborts across the ABI.
+ *   - every data pointer is a DEVICE pointer unless the parameter comment says "host".
+ *   - the library allocates no device memory: scratch is an explicit caller-owned workspace whose
+ *     size the matching *_workspace_bytes() reports.  Kernels are asynchronous on the given stream;
+ *     there is no hidden synchronisation.  Re-entrant for distinct streams + workspaces.
+ *   - row-major contiguous tensors only; leading dimensions are explicit where they may differ.
+ *   - dtype codes: SC_F16 = 0, SC_BF16 = 1, SC_F32 = 2.
+ */
+#ifndef STREAMCHAT_HIP_H
+#define STREAMCHAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sc_stream_t;
+
+enum { SC_F16 = 0, SC_BF16 = 1, SC_F32 = 2 };
+enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC_ERR_UNSUPPORTED = -4 };
+
+#define SC_ABI_VERSION 1
+
+int sc_abi_version(void);
+const char* sc_last_error(void);
+/* host out-params: number of CUs, 1 if the device is gfx950, total HBM bytes */
+int sc_device_info(int* cu_count, int* is_gfx950, size_t* hbm_bytes);
+
+/* ----------------------------------------------------------------------------------------------
+ * Selective-frame k-means.  Replaces `weighted_kmeans_feature` / inner `weighted_kmeans_torch`
+ * (reference utiles.py:291-330, :294-318; callers utiles.py:587, inference_streaming_longva_v2.py:347).
+ *   X          [T, D] row-major, dtype code `dtype` (D = P*Dm = 576*3584 for LongVA frames)
+ *   w          [T] fp32 point weights or NULL (= all ones, reference default :292-293)
+ *   init_idx   [K] int32 rows used as initial centroids (the reference draws torch.randperm :295;
+ *              the draw is an explicit input here so results do not depend on a device RNG)
+ *   reseed_idx [n_reseed] int32 rows consumed in order whenever a cluster is empty
+ *              (reference: random.randint :313); may be NULL if n_reseed == 0
+ *   C          [K, D] fp32 out — centroids as the reference returns them (Q3 semantics)
+ *   labels     [T] int64 out — assignment of the last executed iteration
+ *   wsum       [K] fp32 out — weights_sum of the last update
+ *   info       [4] int32 out: {exit_iter, status (0 ok, 1 = reseed stream exhausted),
+ *              reseeds consumed, reserved}
+ * Lloyd iterations run entirely on the device (no host round trip); iterations after
+ * convergence are skipped by a device-side flag.  Reduction order: "SC-KM1" (DESIGN.md §4),
+ * restated bit-for-bit by oracle/kmeans_oracle.c.
+ */
+size_t sc_kmeans_workspace_bytes(int T, int64_t D, int K);
+int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, const float* w,
+                  const int32_t* init_idx, const int32_t* reseed_idx, int n_reseed,
+                  int max_iter, float tol, float* C, int64_t* labels, float* wsum, int32_t* info,
+                  void* ws, size_t ws_bytes, sc_stream_t stream);
+/* One assignment step against given centroids (the `kmeans_predict` surface of
+ * kmeans_pytorch/__init__.py:130 and torch_kmeans KMeans.predict): labels [T] int64,
+ * dist2 [T, K] fp64 squared Euclidean distances (may be NULL). */
+int sc_kmeans_assign(const void* X, int dtype, int T, int64_t D, int K, const float* C,
+                     int64_t* labels, double* dist2, void* ws, size_t ws_bytes, sc_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Frame preprocessing.  Replaces `process_images` → CLIPImageProcessor.preprocess rescale+normalise
+ * (reference utiles.py:71-87) followed by `.to(torch.float16)` (inference_streaming_longva_v2.py:520).
+ *   hwc   [n, h, w, 3] uint8 RGB frames (already resized/cropped: identity for 336x336 streams)
+ *   mean/std  host float[3]
+ *   out   [n, 3, h, w] fp16:  ((x/255) - mean[c]) / std[c]   (fp32 math, rounded once to fp16)
+ */
+int sc_preprocess_u8(const uint8_t* hwc, int n, int h, int w, const float* mean, const float* std,
+                     void* out_f16, sc_stream_t stream);
+/* Same arithmetic fused with the ViT patch gather (im2col of the Conv2d k=s=patch at
+ * HF CLIPVisionEmbeddings; call site reference clip_encoder.py:76): writes
+ *   out [n * (h/patch) * (w/patch), ld] fp16, column = c*patch*patch + py*patch + px, columns
+ *   [3*patch*patch, ld) zero-filled (ld >= 3*patch*patch, multiple of 8). */
+int sc_preprocess_patchify_u8(const uint8_t* hwc, int n, int h, int w, int patch, const float* mean,
+                              const float* std, void* out_f16, int ld, sc_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Similarity top-k.  Replaces `cos_sim` + strict-> running argmax of the tree search
+ * (reference utiles.py:732,738-740,768-771) and the FAISS flat-L2 `similarity_search_with_score`
+ * of the dialogue memory (memory_bank/memory_retrieval/local_doc_qa.py:270).
+ *   q [d] fp32, docs [M, d] fp32; metric 0 = cosine (descending), 1 = squared L2 (ascending)
+ *   idx [k] int32, score [k] fp32 out, best first; ties -> lowest index.  k <= 64.
+ */
+int sc_sim_topk(const float* q, const float* docs, int M, int d, int k, int metric, int32_t* idx,
+                float* score, sc_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Dense building blocks of the encoders (ViT-L/14-336 + mlp2x_gelu projector, BERT text encoders,
+ * Qwen2 LLM).  They replace the third-party transformers==4.37.2 modules the reference calls at
+ * longva/model/multimodal_encoder/clip_encoder.py:76, multimodal_projector/builder.py:41-48,
+ * utiles.py:707,728 and longva/model/language_model/llava_qwen.py:155.
+ */
+enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2 };
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N]).  fp16 in, fp32 accumulate (MFMA),
+ * fp16 out (out_f32 = 0) or fp32 out (out_f32 = 1).  W has the torch.nn.Linear layout [N, K].
+ * lda / ldr / ldc in elements.  Requirements: K % 64 == 0, N % 128 == 0, A and W 16-byte aligned,
+ * lda % 8 == 0.  M is arbitrary.  bias and residual may be NULL. */
+int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const void* residual, int ldr,
+                void* C, int ldc, int M, int N, int K, int epilogue, int out_f32, sc_stream_t stream);
+/* y = LayerNorm(x) * gamma + beta over the last dim, fp32 statistics; [rows, cols] fp16, cols % 8 == 0,
+ * cols <= 4096. */
+int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y,
+                     int ldy, int rows, int cols, sc_stream_t stream);
+/* Qwen2 RMSNorm: y = gamma * fp16(x * rsqrt(mean(x^2) + eps)), fp32 statistics. */
+int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float eps, void* y, int ldy, int rows,
+                   int cols, sc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREAMCHAT_HIP_H */

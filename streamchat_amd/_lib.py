@@ -1,0 +1,83 @@
+"""ctypes binding of libstreamchat_hip.so — the ONLY compute path of the package.
+
+There is deliberately no fallback: if the shared library is missing or a symbol cannot be bound the
+import fails loudly, and every wrapper refuses non-CUDA tensors.  Signatures mirror
+include/streamchat_hip.h one to one."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstreamchat_hip.so")
+
+
+class StreamChatHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
+SIGNATURES = {
+    "sc_abi_version": (c_int, []),
+    "sc_last_error": (c_char_p, []),
+    "sc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
+    "sc_kmeans_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "sc_kmeans_fit": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_kmeans_assign": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
+    "sc_preprocess_patchify_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p]),
+    "sc_gemm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sc_layernorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sc_rmsnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sc_sim_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load and bind the library (raises StreamChatHipError if it is not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StreamChatHipError(
+            f"{LIB_PATH} not found: build it with `python -m streamchat_amd.build` (hipcc, gfx950). "
+            "streamchat_amd has no CPU / PyTorch fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise StreamChatHipError(f"libstreamchat_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sc_abi_version() != 1:
+        raise StreamChatHipError(f"ABI version mismatch: library {lib.sc_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sc_last_error()
+        raise StreamChatHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device pointer of a CUDA tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise StreamChatHipError("streamchat_amd kernels take CUDA (HIP) tensors only; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise StreamChatHipError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+DTYPE_CODE = {"torch.float16": 0, "torch.bfloat16": 1, "torch.float32": 2}

@@ -1,0 +1,564 @@
+// Selective-frame k-means for gfx950 (CDNA4) — the HBM-streaming replacement of the reference's
+// `weighted_kmeans_feature` (utiles.py:291-330).  Each "point" is a whole frame of
+// D = 576*3584 = 2,064,384 features and K is tiny (5..8), so this is a pure streaming reduce:
+// the reference's [T,K,D] broadcast temporary (utiles.py:299, 8.3 GB at T=400) is never formed.
+//
+// Kernels (one Lloyd iteration = assign -> reduce -> labels/order -> update -> decide):
+//   km_assign   one wave per 512-column chunk; centroid slice lives in VGPRs, rows stream through
+//               as 16-byte/lane coalesced loads (1 KiB per wave-instruction); the TT*KB fp32 lane
+//               partials of a row group are reduced across the wave with a halving butterfly
+//               (v_permlane32_swap / v_permlane16_swap + 4 shuffle levels: ~2.5 ops per value
+//               instead of 12) and written as one coalesced 256-byte line per group.
+//   km_reduce   fp64 two-level (32 segments) sum of the per-chunk partials.
+//   km_labels   argmin (first minimum), stable counting sort of rows by label, W[k].
+//   km_update   one wave per chunk: per cluster, rows in ascending order, fp32 sequential
+//               weighted sum / W; shift partials for the convergence test.
+//   km_decide   sum_k ||C_i - C'||_2 < tol ? -> device-side `done` flag (no host round trip).
+// The arithmetic order is the "SC-KM1" spec shared bit-for-bit with oracle/kmeans_oracle.c.
+// Compiled with -ffp-contract=off: every fma below is explicit.
+#include "sc_common.h"
+
+namespace {
+
+constexpr int CH = 512;      // columns per chunk = 64 lanes x 8 elements
+constexpr int NSEG = 32;     // fp64 segments
+constexpr int WPB = 4;       // waves per block in the streaming kernels
+
+struct KmState {
+    int done, exit_iter, cur, reseed_pos, status, n_empty, pad0, pad1;
+};
+
+template <typename Tag> struct Raw8;
+template <> struct Raw8<ScF16> {
+    uint4 a;
+    __device__ __forceinline__ void load(const void* b, size_t off) { a = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(b) + off); }
+    __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void unpack(float (&o)[8]) const {
+        sc_h8 v = __builtin_bit_cast(sc_h8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    }
+};
+template <> struct Raw8<ScBF16> {
+    uint4 a;
+    __device__ __forceinline__ void load(const void* b, size_t off) { a = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(b) + off); }
+    __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void unpack(float (&o)[8]) const {
+        unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    }
+};
+template <> struct Raw8<ScF32> {
+    uint4 a, b;
+    __device__ __forceinline__ void load(const void* p, size_t off) {
+        const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p) + off);
+        a = q[0]; b = q[1];
+    }
+    __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); b = a; }
+    __device__ __forceinline__ void unpack(float (&o)[8]) const {
+        o[0] = __uint_as_float(a.x); o[1] = __uint_as_float(a.y); o[2] = __uint_as_float(a.z); o[3] = __uint_as_float(a.w);
+        o[4] = __uint_as_float(b.x); o[5] = __uint_as_float(b.y); o[6] = __uint_as_float(b.z); o[7] = __uint_as_float(b.w);
+    }
+};
+
+// generic (unaligned D) 8-element fetch with per-element bounds
+template <typename Tag>
+__device__ __forceinline__ void load8_guard(const void* base, size_t rowoff, int64_t col, int64_t D, float (&o)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (col + e < D) ? sc_load1<Tag>(base, rowoff + (size_t)(col + e)) : 0.f;
+}
+
+template <int M>
+__device__ __forceinline__ void bfly_step(float (&v)[64], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float send = up ? v[i] : v[i + M];
+        const float keep = up ? v[i + M] : v[i];
+        v[i] = keep + __shfl_xor(send, M, 64);
+    }
+}
+
+// Halving butterfly: on entry lane L holds 64 values v[i] (item i, this lane's partial);
+// on exit v[0] of lane L holds the SC-KM1 tree sum over all 64 lanes of item L.
+__device__ __forceinline__ void butterfly64(float (&v)[64], int lane) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    bfly_step<8>(v, lane);
+    bfly_step<4>(v, lane);
+    bfly_step<2>(v, lane);
+    bfly_step<1>(v, lane);
+}
+
+__host__ __device__ constexpr int tt_for(int kb) { return (64 / kb) < 16 ? (64 / kb) : 16; }
+
+// ---------------------------------------------------------------------------------------------
+template <typename Tag, int KB, bool VEC>
+__global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X, const float* __restrict__ Ca,
+                                                      const float* __restrict__ Cb, const KmState* __restrict__ st,
+                                                      float* __restrict__ partial, int T, int64_t D, int K, int k0,
+                                                      int64_t nchunks) {
+    constexpr int TT = tt_for(KB);
+    if (st->done) return;
+    const float* __restrict__ C = st->cur ? Cb : Ca;
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int64_t col = c * CH + lane * 8;
+    const bool active = col < D;
+    const size_t I = (size_t)T * (size_t)K;
+
+    float cr[KB][8];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        if (VEC) {
+            if (active) sc_load8<ScF32>(C, (size_t)(k0 + k) * (size_t)D + (size_t)col, cr[k]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cr[k][e] = 0.f;
+            }
+        } else {
+            load8_guard<ScF32>(C, (size_t)(k0 + k) * (size_t)D, col, D, cr[k]);
+        }
+    }
+
+    const int ngroups = (T + TT - 1) / TT;
+    Raw8<Tag> cur[TT], nxt[TT];
+    float xg[VEC ? 1 : TT][8];   // unaligned path keeps converted rows instead of raw vectors
+    (void)xg;
+
+    auto load_group = [&](int g, Raw8<Tag>(&buf)[TT]) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = g * TT + tt;
+            if (t < T && active) buf[tt].load(X, (size_t)t * (size_t)D + (size_t)col);
+            else buf[tt].zero();
+        }
+    };
+    if (VEC) load_group(0, cur);
+
+    for (int g = 0; g < ngroups; ++g) {
+        if (VEC && g + 1 < ngroups) load_group(g + 1, nxt);
+        float p[64];
+#pragma unroll
+        for (int i = TT * KB; i < 64; ++i) p[i] = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float x[8];
+            if (VEC) cur[tt].unpack(x);
+            else {
+                const int t = g * TT + tt;
+                if (t < T) load8_guard<Tag>(X, (size_t)t * (size_t)D, col, D, x);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float d0 = x[e] - cr[k][e];
+                    const float d1 = x[e + 1] - cr[k][e + 1];
+                    a0 = __builtin_fmaf(d0, d0, a0);
+                    a1 = __builtin_fmaf(d1, d1, a1);
+                }
+                p[tt * KB + k] = a0 + a1;
+            }
+        }
+        butterfly64(p, lane);
+        if (lane < TT * KB) {
+            const int tt = lane / KB, k = lane - tt * KB;
+            const int t = g * TT + tt;
+            if (t < T) partial[(size_t)c * I + (size_t)t * K + (k0 + k)] = p[0];
+        }
+        if (VEC) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) cur[tt] = nxt[tt];
+        }
+    }
+}
+
+// level-1 fp64 reduce: seg[s][item] = sum_{c in segment s, ascending} partial[c][item]
+__global__ void km_reduce(const float* __restrict__ partial, const KmState* __restrict__ st, double* __restrict__ seg,
+                          size_t I, int64_t nchunks, int check_done) {
+    if (check_done && st->done) return;
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= I) return;
+    const int s = blockIdx.y;
+    const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
+    int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
+    if (hi > nchunks) hi = nchunks;
+    double a = 0.0;
+    for (int64_t c = lo; c < hi; ++c) a += (double)partial[(size_t)c * I + item];
+    seg[(size_t)s * I + item] = a;
+}
+
+// single block: dist2 totals -> labels (first minimum) -> stable order by label, W[k], empties
+__global__ __launch_bounds__(256) void km_labels(const double* __restrict__ seg, KmState* __restrict__ st,
+                                                 const float* __restrict__ w, int* __restrict__ labels32,
+                                                 int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
+                                                 int* __restrict__ empty_rank, double* __restrict__ dist2_out, int T, int K,
+                                                 int check_done) {
+    if (check_done && st->done) return;
+    const size_t I = (size_t)T * K;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        int best = 0;
+        double bv = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double tot = 0.0;
+            for (int s = 0; s < NSEG; ++s) tot += seg[(size_t)s * I + (size_t)t * K + k];
+            if (dist2_out) dist2_out[(size_t)t * K + k] = tot;
+            if (k == 0 || tot < bv) { bv = tot; best = k; }
+        }
+        labels32[t] = best;
+    }
+    __syncthreads();
+    // counts + sequential fp32 weight sums (ascending t), one thread per cluster
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int n = 0;
+        float ws = 0.f;
+        for (int t = 0; t < T; ++t)
+            if (labels32[t] == k) { ++n; ws = ws + (w ? w[t] : 1.0f); }
+        start[k + 1] = n;   // temporarily the count
+        W[k] = ws;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        start[0] = 0;
+        int ne = 0;
+        for (int k = 0; k < K; ++k) {
+            start[k + 1] += start[k];
+            empty_rank[k] = (W[k] > 0.f) ? -1 : ne++;
+        }
+        st->n_empty = ne;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int pos = start[k];
+        for (int t = 0; t < T; ++t)
+            if (labels32[t] == k) order[pos++] = t;
+    }
+}
+
+// one wave per chunk: new centroids + shift partials
+template <typename Tag, bool VEC>
+__global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X, float* __restrict__ Ca, float* __restrict__ Cb,
+                                                      KmState* __restrict__ st, const float* __restrict__ w,
+                                                      const int* __restrict__ order, const int* __restrict__ start,
+                                                      const float* __restrict__ W, const int* __restrict__ empty_rank,
+                                                      const int* __restrict__ reseed_idx, int n_reseed,
+                                                      float* __restrict__ dpart, int T, int64_t D, int K, int64_t nchunks) {
+    if (st->done) return;
+    const float* __restrict__ Cold = st->cur ? Cb : Ca;
+    float* __restrict__ Cnew = st->cur ? Ca : Cb;
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int64_t col = c * CH + lane * 8;
+    const bool active = col < D;
+    const int rbase = st->reseed_pos;
+
+    for (int k = 0; k < K; ++k) {
+        float cn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cn[e] = 0.f;
+        const float Wk = W[k];
+        if (Wk > 0.f) {
+            const int lo = start[k], hi = start[k + 1];
+            constexpr int U = 8;
+            for (int i0 = lo; i0 < hi; i0 += U) {
+                float x[U][8];
+                float wt[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u;
+                    if (i < hi) {
+                        const int t = order[i];
+                        wt[u] = w ? w[t] : 1.0f;
+                        if (VEC) {
+                            if (active) sc_load8<Tag>(X, (size_t)t * (size_t)D + (size_t)col, x[u]);
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
+                            }
+                        } else load8_guard<Tag>(X, (size_t)t * (size_t)D, col, D, x[u]);
+                    } else {
+                        wt[u] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (i0 + u < hi) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cn[e] = cn[e] + wt[u] * x[u][e];   // mul, then add: no contraction
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cn[e] = cn[e] / Wk;
+        } else {
+            const int pos = rbase + empty_rank[k];
+            int r = 0;
+            if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
+            if (r < 0 || r >= T) r = 0;
+            if (VEC) { if (active) sc_load8<Tag>(X, (size_t)r * (size_t)D + (size_t)col, cn); }
+            else load8_guard<Tag>(X, (size_t)r * (size_t)D, col, D, cn);
+        }
+        float co[8];
+        if (VEC) {
+            if (active) sc_load8<ScF32>(Cold, (size_t)k * (size_t)D + (size_t)col, co);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) co[e] = 0.f;
+            }
+        } else load8_guard<ScF32>(Cold, (size_t)k * (size_t)D, col, D, co);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float d0 = co[e] - cn[e], d1 = co[e + 1] - cn[e + 1];
+            a0 = __builtin_fmaf(d0, d0, a0);
+            a1 = __builtin_fmaf(d1, d1, a1);
+        }
+        const float wp = sc_wave_tree_sum(a0 + a1);
+        if (lane == 0) dpart[(size_t)c * K + k] = wp;
+        if (VEC) {
+            if (active) {
+                sc_f4* dst = reinterpret_cast<sc_f4*>(Cnew + (size_t)k * (size_t)D + (size_t)col);
+                dst[0] = sc_f4{cn[0], cn[1], cn[2], cn[3]};
+                dst[1] = sc_f4{cn[4], cn[5], cn[6], cn[7]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col + e < D) Cnew[(size_t)k * (size_t)D + (size_t)(col + e)] = cn[e];
+        }
+    }
+}
+
+// single block: shift = sum_k sqrt(total_k); decide convergence; advance state
+__global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart, KmState* __restrict__ st, int K, int64_t nchunks,
+                                                 int iter, int max_iter, float tol, int n_reseed) {
+    if (st->done) return;
+    __shared__ double segs[NSEG * 64];   // K <= 64 per pass
+    __shared__ double tot[64];
+    const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
+    double diff = 0.0;
+    for (int kb = 0; kb < K; kb += 64) {
+        const int kn = (K - kb) < 64 ? (K - kb) : 64;
+        for (int p = threadIdx.x; p < NSEG * kn; p += blockDim.x) {
+            const int s = p / kn, k = kb + p % kn;
+            int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
+            if (hi > nchunks) hi = nchunks;
+            double a = 0.0;
+            for (int64_t c = lo; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
+            segs[s * 64 + (k - kb)] = a;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < kn) {
+            double t = 0.0;
+            for (int s = 0; s < NSEG; ++s) t += segs[s * 64 + threadIdx.x];
+            tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < kn; ++k) diff += sqrt(tot[k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (st->n_empty > 0) {
+            if (st->reseed_pos + st->n_empty > n_reseed) st->status = 1;
+            st->reseed_pos += st->n_empty;
+        }
+        if (diff < (double)tol) {
+            st->done = 1;
+            st->exit_iter = iter;
+        } else {
+            st->cur ^= 1;
+            if (iter == max_iter - 1) { st->done = 1; st->exit_iter = iter; }
+        }
+    }
+}
+
+template <typename Tag>
+__global__ void km_init(const void* __restrict__ X, const int* __restrict__ init_idx, float* __restrict__ C, KmState* st,
+                        int T, int64_t D, int K) {
+    const size_t n = (size_t)K * (size_t)D;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 0; st->exit_iter = 0; st->cur = 0; st->reseed_pos = 0; st->status = 0; st->n_empty = 0; }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / (size_t)D);
+        const size_t j = i - (size_t)k * (size_t)D;
+        int r = init_idx[k];
+        if (r < 0 || r >= T) r = 0;
+        C[i] = sc_load1<Tag>(X, (size_t)r * (size_t)D + j);
+    }
+}
+
+__global__ void km_finalize(const float* __restrict__ Ca, const float* __restrict__ Cb, const KmState* __restrict__ st,
+                            const int* __restrict__ labels32, const float* __restrict__ W, float* __restrict__ Cout,
+                            int64_t* __restrict__ labels, float* __restrict__ wsum, int* __restrict__ info, int T, int64_t D, int K) {
+    const float* C = st->cur ? Cb : Ca;
+    const size_t n = (size_t)K * (size_t)D;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cout) | reinterpret_cast<uintptr_t>(C)) & 15) == 0) {
+        const sc_f4* src = reinterpret_cast<const sc_f4*>(C);
+        sc_f4* dst = reinterpret_cast<sc_f4*>(Cout);
+        for (size_t i = gid; i < n / 4; i += gsz) dst[i] = src[i];
+    } else {
+        for (size_t i = gid; i < n; i += gsz) Cout[i] = C[i];
+    }
+    for (size_t t = gid; t < (size_t)T; t += gsz) labels[t] = labels32[t];
+    for (size_t k = gid; k < (size_t)K; k += gsz) wsum[k] = W[k];
+    if (gid == 0) { info[0] = st->exit_iter; info[1] = st->status; info[2] = st->reseed_pos; info[3] = 0; }
+}
+
+__global__ void km_set_state(KmState* st, int cur) {
+    st->done = 0; st->exit_iter = 0; st->cur = cur; st->reseed_pos = 0; st->status = 0; st->n_empty = 0;
+}
+__global__ void km_labels_out(const int* __restrict__ labels32, int64_t* __restrict__ labels, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) labels[t] = labels32[t];
+}
+
+// ---- workspace carve --------------------------------------------------------------------------
+struct KmWs {
+    KmState* st; float* Ca; float* Cb; float* partial; double* seg; float* dpart; int* labels32; int* order; int* start;
+    float* W; int* empty_rank; size_t bytes;
+};
+KmWs carve(void* base, int T, int64_t D, int K) {
+    const int64_t nch = (D + CH - 1) / CH;
+    const size_t I = (size_t)T * K;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = sc_align_up(off + bytes, 256); return p ? (void*)(p + o) : (void*)nullptr; };
+    KmWs w;
+    w.st = (KmState*)take(sizeof(KmState));
+    w.Ca = (float*)take(sizeof(float) * (size_t)K * D);
+    w.Cb = (float*)take(sizeof(float) * (size_t)K * D);
+    w.partial = (float*)take(sizeof(float) * (size_t)nch * I);
+    w.seg = (double*)take(sizeof(double) * NSEG * I);
+    w.dpart = (float*)take(sizeof(float) * (size_t)nch * K);
+    w.labels32 = (int*)take(sizeof(int) * T);
+    w.order = (int*)take(sizeof(int) * T);
+    w.start = (int*)take(sizeof(int) * (K + 1));
+    w.W = (float*)take(sizeof(float) * K);
+    w.empty_rank = (int*)take(sizeof(int) * K);
+    w.bytes = off;
+    return w;
+}
+
+template <typename Tag, int KB>
+void launch_assign_kb(bool vec, const void* X, const KmWs& w, int T, int64_t D, int K, int k0, int64_t nch, hipStream_t s) {
+    const dim3 grid((unsigned)((nch + WPB - 1) / WPB)), block(WPB * 64);
+    if (vec) hipLaunchKernelGGL((km_assign<Tag, KB, true>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.partial, T, D, K, k0, nch);
+    else hipLaunchKernelGGL((km_assign<Tag, KB, false>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.partial, T, D, K, k0, nch);
+}
+template <typename Tag>
+void launch_assign(bool vec, const void* X, const KmWs& w, int T, int64_t D, int K, int64_t nch, hipStream_t s) {
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int kb = (K - k0) < 16 ? (K - k0) : 16;
+        switch (kb) {
+#define SC_CASE(n) case n: launch_assign_kb<Tag, n>(vec, X, w, T, D, K, k0, nch, s); break;
+            SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
+            SC_CASE(9) SC_CASE(10) SC_CASE(11) SC_CASE(12) SC_CASE(13) SC_CASE(14) SC_CASE(15) SC_CASE(16)
+#undef SC_CASE
+        }
+    }
+}
+
+template <typename Tag>
+int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int32_t* init_idx, const int32_t* reseed_idx,
+             int n_reseed, int max_iter, float tol, float* C, int64_t* labels, float* wsum, int32_t* info, void* ws,
+             hipStream_t s) {
+    const KmWs w = carve(ws, T, D, K);
+    const int64_t nch = (D + CH - 1) / CH;
+    const size_t I = (size_t)T * K;
+    const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    hipLaunchKernelGGL((km_init<Tag>), dim3(1024), dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+    const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
+    const dim3 rgrid((unsigned)((I + 255) / 256), NSEG);
+    for (int it = 0; it < max_iter; ++it) {
+        launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 1);
+        hipLaunchKernelGGL(km_labels, dim3(1), dim3(256), 0, s, w.seg, w.st, wts, w.labels32, w.order, w.start, w.W,
+                           w.empty_rank, (double*)nullptr, T, K, 1);
+        if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
+                                    w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch);
+        else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
+                                w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch);
+        hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dpart, w.st, K, nch, it, max_iter, tol, n_reseed);
+    }
+    hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
+    SC_CHECK_LAUNCH("sc_kmeans_fit");
+    return SC_OK;
+}
+
+template <typename Tag>
+int assign_impl(const void* X, int T, int64_t D, int K, const float* C, int64_t* labels, double* dist2, void* ws, hipStream_t s) {
+    KmWs w = carve(ws, T, D, K);
+    const int64_t nch = (D + CH - 1) / CH;
+    const size_t I = (size_t)T * K;
+    const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    hipLaunchKernelGGL(km_set_state, dim3(1), dim3(1), 0, s, w.st, 0);
+    w.Ca = const_cast<float*>(C);   // read-only use: state.cur == 0 selects Ca
+    launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+    hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 0);
+    hipLaunchKernelGGL(km_labels, dim3(1), dim3(256), 0, s, w.seg, w.st, (const float*)nullptr, w.labels32, w.order, w.start,
+                       w.W, w.empty_rank, dist2, T, K, 0);
+    hipLaunchKernelGGL(km_labels_out, dim3((T + 255) / 256), dim3(256), 0, s, w.labels32, labels, T);
+    SC_CHECK_LAUNCH("sc_kmeans_assign");
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sc_kmeans_workspace_bytes(int T, int64_t D, int K) {
+    if (T <= 0 || D <= 0 || K <= 0) return 0;
+    return carve(nullptr, T, D, K).bytes;
+}
+
+extern "C" int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, const float* w, const int32_t* init_idx,
+                             const int32_t* reseed_idx, int n_reseed, int max_iter, float tol, float* C, int64_t* labels,
+                             float* wsum, int32_t* info, void* ws, size_t ws_bytes, sc_stream_t stream) {
+    SC_REQUIRE(X && init_idx && C && labels && wsum && info && ws, "sc_kmeans_fit: null pointer argument");
+    SC_REQUIRE(T > 0 && D > 0 && K > 0 && max_iter > 0, "sc_kmeans_fit: T, D, K, max_iter must be positive");
+    SC_REQUIRE(n_reseed >= 0 && (n_reseed == 0 || reseed_idx), "sc_kmeans_fit: n_reseed > 0 needs reseed_idx");
+    if (ws_bytes < sc_kmeans_workspace_bytes(T, D, K))
+        return sc_fail(SC_ERR_WORKSPACE, "sc_kmeans_fit: workspace %zu < required %zu", ws_bytes, sc_kmeans_workspace_bytes(T, D, K));
+    SC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "sc_kmeans_fit: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case SC_F16: return fit_impl<ScF16>(X, T, D, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C, labels, wsum, info, ws, s);
+        case SC_BF16: return fit_impl<ScBF16>(X, T, D, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C, labels, wsum, info, ws, s);
+        case SC_F32: return fit_impl<ScF32>(X, T, D, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C, labels, wsum, info, ws, s);
+    }
+    return sc_fail(SC_ERR_ARG, "sc_kmeans_fit: unknown dtype %d", dtype);
+}
+
+extern "C" int sc_kmeans_assign(const void* X, int dtype, int T, int64_t D, int K, const float* C, int64_t* labels, double* dist2,
+                                void* ws, size_t ws_bytes, sc_stream_t stream) {
+    SC_REQUIRE(X && C && labels && ws, "sc_kmeans_assign: null pointer argument");
+    SC_REQUIRE(T > 0 && D > 0 && K > 0, "sc_kmeans_assign: T, D, K must be positive");
+    if (ws_bytes < sc_kmeans_workspace_bytes(T, D, K))
+        return sc_fail(SC_ERR_WORKSPACE, "sc_kmeans_assign: workspace %zu < required %zu", ws_bytes, sc_kmeans_workspace_bytes(T, D, K));
+    SC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "sc_kmeans_assign: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case SC_F16: return assign_impl<ScF16>(X, T, D, K, C, labels, dist2, ws, s);
+        case SC_BF16: return assign_impl<ScBF16>(X, T, D, K, C, labels, dist2, ws, s);
+        case SC_F32: return assign_impl<ScF32>(X, T, D, K, C, labels, dist2, ws, s);
+    }
+    return sc_fail(SC_ERR_ARG, "sc_kmeans_assign: unknown dtype %d", dtype);
+}

@@ -1,0 +1,116 @@
+// Row normalisations (HBM-bound): LayerNorm (CLIP / BERT, fp32 statistics as torch.nn.LayerNorm does for
+// fp16 inputs) and RMSNorm (Qwen2: x.float() -> x*rsqrt(mean(x^2)+eps) -> .to(fp16) -> * weight;
+// transformers modeling_qwen2.py Qwen2RMSNorm).  One wave per row, 16-byte loads, the row stays in
+// registers between the statistics pass and the write (one HBM read + one write per element).
+#include "sc_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// NV = 16-byte vectors per lane (cols <= NV*512)
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void k_norm(const _Float16* __restrict__ x, int ldx, const _Float16* __restrict__ gamma,
+                                              const _Float16* __restrict__ beta, float eps, _Float16* __restrict__ y, int ldy, int rows,
+                                              int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const _Float16* xr = x + (size_t)row * (size_t)ldx;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            sc_h8 h = *reinterpret_cast<const sc_h8*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)h[e]; s += RMS ? v[i][e] * v[i][e] : v[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / (float)cols + eps);
+    } else {
+        mean = s / (float)cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < cols) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)cols + eps);
+    }
+    _Float16* yr = y + (size_t)row * (size_t)ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            sc_h8 g = *reinterpret_cast<const sc_h8*>(gamma + c);
+            sc_h8 o;
+            if (RMS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const _Float16 t = (_Float16)(v[i][e] * rstd); o[e] = (_Float16)((float)g[e] * (float)t); }
+            } else {
+                sc_h8 b = *reinterpret_cast<const sc_h8*>(beta + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            }
+            *reinterpret_cast<sc_h8*>(yr + c) = o;
+        }
+    }
+}
+
+template <bool RMS>
+int launch_norm(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y, int ldy, int rows, int cols,
+                hipStream_t s, const char* name) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nv = (cols + 511) / 512;
+#define SC_NORM(NV)                                                                                                         \
+    hipLaunchKernelGGL((k_norm<NV, RMS>), grid, block, 0, s, (const _Float16*)x, ldx, (const _Float16*)gamma, (const _Float16*)beta, eps, \
+                       (_Float16*)y, ldy, rows, cols)
+    if (nv <= 1) SC_NORM(1);
+    else if (nv <= 2) SC_NORM(2);
+    else if (nv <= 4) SC_NORM(4);
+    else if (nv <= 8) SC_NORM(8);
+    else return sc_fail(SC_ERR_UNSUPPORTED, "%s: cols %d > 4096 unsupported", name, cols);
+#undef SC_NORM
+    SC_CHECK_LAUNCH(name);
+    return SC_OK;
+}
+
+int check_norm_args(const void* x, int ldx, const void* gamma, void* y, int ldy, int rows, int cols, const char* name) {
+    SC_REQUIRE(x && gamma && y, "%s: null pointer argument", name);
+    SC_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0, "%s: cols must be a positive multiple of 8", name);
+    SC_REQUIRE(ldx >= cols && ldy >= cols && ldx % 8 == 0 && ldy % 8 == 0, "%s: leading dimensions must be >= cols and multiples of 8", name);
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0,
+               "%s: pointers must be 16-byte aligned", name);
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y, int ldy, int rows,
+                                int cols, sc_stream_t stream) {
+    if (int rc = check_norm_args(x, ldx, gamma, y, ldy, rows, cols, "sc_layernorm_f16")) return rc;
+    SC_REQUIRE(beta && (reinterpret_cast<uintptr_t>(beta) & 15) == 0, "sc_layernorm_f16: beta must be non-null and 16-byte aligned");
+    return launch_norm<false>(x, ldx, gamma, beta, eps, y, ldy, rows, cols, (hipStream_t)stream, "sc_layernorm_f16");
+}
+
+extern "C" int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float eps, void* y, int ldy, int rows, int cols,
+                              sc_stream_t stream) {
+    if (int rc = check_norm_args(x, ldx, gamma, y, ldy, rows, cols, "sc_rmsnorm_f16")) return rc;
+    return launch_norm<true>(x, ldx, gamma, nullptr, eps, y, ldy, rows, cols, (hipStream_t)stream, "sc_rmsnorm_f16");
+}

@@ -1,0 +1,206 @@
+"""Thin tensor-level wrappers over the C ABI (include/streamchat_hip.h).
+
+PyTorch is used for device memory, streams and nothing else: every function here launches
+hand-written gfx950 kernels on `torch.cuda.current_stream()` with caller-visible tensors as
+buffers.  No function has a PyTorch / CPU fallback."""
+import ctypes
+from ctypes import c_float, c_int, c_int64, c_size_t
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr, StreamChatHipError
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # openai/clip-vit-large-patch14-336 preprocessor_config
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise StreamChatHipError("streamchat_amd kernels take CUDA (HIP) tensors only; there is no CPU fallback")
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _lib.DTYPE_CODE[str(t.dtype)]
+    except KeyError:
+        raise StreamChatHipError(f"unsupported dtype {t.dtype}")
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch (caller-owned memory handed to the library; 256-byte aligned)."""
+    key = (torch.device(device).index or 0)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def device_info():
+    lib = _lib.load()
+    cu, ok, mem = c_int(0), c_int(0), c_size_t(0)
+    check(lib.sc_device_info(ctypes.byref(cu), ctypes.byref(ok), ctypes.byref(mem)), "sc_device_info")
+    return dict(cu_count=cu.value, is_gfx950=bool(ok.value), hbm_bytes=mem.value)
+
+
+# ------------------------------------------------------------------------------------------------
+def kmeans_fit(X: torch.Tensor, K: int, init_idx, reseed_idx=None, weights=None, max_iter: int = 10, tol: float = 1e-4):
+    """Lloyd k-means on the device (reference utiles.py:294-318 semantics, fp32-canonical).
+
+    X [T, D] f16/bf16/f32 CUDA; init_idx [K] ints; reseed_idx optional ints consumed on empty clusters.
+    Returns (centroids [K, D] fp32, labels [T] int64, wsum [K] fp32, info [4] int32) — all CUDA tensors,
+    nothing is synchronised."""
+    _require_cuda(X)
+    lib = _lib.load()
+    if X.dim() != 2:
+        raise StreamChatHipError("kmeans_fit: X must be [T, D]")
+    X = X.contiguous()
+    T, D = X.shape
+    dev = X.device
+    init = torch.as_tensor(init_idx, dtype=torch.int32).to(dev).contiguous()
+    if init.numel() != K:
+        raise StreamChatHipError("kmeans_fit: init_idx must have K entries")
+    rs = None if reseed_idx is None else torch.as_tensor(reseed_idx, dtype=torch.int32).to(dev).contiguous()
+    w = None if weights is None else weights.to(device=dev, dtype=torch.float32).contiguous()
+    C = torch.empty((K, D), dtype=torch.float32, device=dev)
+    labels = torch.empty(T, dtype=torch.int64, device=dev)
+    wsum = torch.empty(K, dtype=torch.float32, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    need = lib.sc_kmeans_workspace_bytes(T, D, K)
+    ws = _workspace(need, dev)
+    with torch.cuda.device(dev):
+        check(lib.sc_kmeans_fit(ptr(X), _code(X), T, c_int64(D), K, ptr(w), ptr(init), ptr(rs), 0 if rs is None else rs.numel(),
+                                max_iter, c_float(tol), ptr(C), ptr(labels), ptr(wsum), ptr(info), ptr(ws), c_size_t(ws.numel()),
+                                stream_ptr(dev)), "sc_kmeans_fit")
+    return C, labels, wsum, info
+
+
+def kmeans_assign(X: torch.Tensor, C: torch.Tensor, return_dist2: bool = False):
+    """labels [T] int64 (and optionally dist2 [T, K] fp64) of rows X against fp32 centroids C."""
+    _require_cuda(X, C)
+    lib = _lib.load()
+    X = X.contiguous()
+    C = C.to(torch.float32).contiguous()
+    T, D = X.shape
+    K = C.shape[0]
+    dev = X.device
+    labels = torch.empty(T, dtype=torch.int64, device=dev)
+    d2 = torch.empty((T, K), dtype=torch.float64, device=dev) if return_dist2 else None
+    ws = _workspace(lib.sc_kmeans_workspace_bytes(T, D, K), dev)
+    with torch.cuda.device(dev):
+        check(lib.sc_kmeans_assign(ptr(X), _code(X), T, c_int64(D), K, ptr(C), ptr(labels), ptr(d2), ptr(ws), c_size_t(ws.numel()),
+                                   stream_ptr(dev)), "sc_kmeans_assign")
+    return (labels, d2) if return_dist2 else labels
+
+
+# ------------------------------------------------------------------------------------------------
+def _f3(v):
+    return (c_float * 3)(*[float(x) for x in v])
+
+
+def preprocess_u8(frames: torch.Tensor, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """uint8 [N, H, W, 3] -> fp16 [N, 3, H, W], ((x/255)-mean)/std  (reference utiles.py:71-87 + .to(fp16))."""
+    _require_cuda(frames)
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise StreamChatHipError("preprocess_u8: frames must be uint8 [N, H, W, 3]")
+    frames = frames.contiguous()
+    n, h, w, _ = frames.shape
+    out = torch.empty((n, 3, h, w), dtype=torch.float16, device=frames.device)
+    with torch.cuda.device(frames.device):
+        check(lib.sc_preprocess_u8(ptr(frames), n, h, w, _f3(mean), _f3(std), ptr(out), stream_ptr(frames.device)), "sc_preprocess_u8")
+    return out
+
+
+def preprocess_patchify_u8(frames: torch.Tensor, patch: int, ld: int, mean=CLIP_MEAN, std=CLIP_STD, out=None) -> torch.Tensor:
+    """uint8 [N, H, W, 3] -> fp16 patch rows [N*(H/p)*(W/p), ld] (normalised, im2col order c,py,px; zero padded)."""
+    _require_cuda(frames)
+    lib = _lib.load()
+    frames = frames.contiguous()
+    n, h, w, _ = frames.shape
+    rows = n * (h // patch) * (w // patch)
+    if out is None:
+        out = torch.empty((rows, ld), dtype=torch.float16, device=frames.device)
+    with torch.cuda.device(frames.device):
+        check(lib.sc_preprocess_patchify_u8(ptr(frames), n, h, w, patch, _f3(mean), _f3(std), ptr(out), ld, stream_ptr(frames.device)),
+              "sc_preprocess_patchify_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def sim_topk(q: torch.Tensor, docs: torch.Tensor, k: int = 1, metric: str = "cos"):
+    """(idx [k] int32, score [k] fp32) of the k best documents; cosine (desc) or squared L2 (asc); ties -> lowest index."""
+    _require_cuda(q, docs)
+    lib = _lib.load()
+    q = q.to(torch.float32).reshape(-1).contiguous()
+    docs = docs.to(torch.float32).contiguous()
+    M, d = docs.shape
+    if q.numel() != d:
+        raise StreamChatHipError("sim_topk: q and docs disagree on d")
+    idx = torch.empty(k, dtype=torch.int32, device=docs.device)
+    score = torch.empty(k, dtype=torch.float32, device=docs.device)
+    with torch.cuda.device(docs.device):
+        check(lib.sc_sim_topk(ptr(q), ptr(docs), M, d, k, 0 if metric == "cos" else 1, ptr(idx), ptr(score), stream_ptr(docs.device)),
+              "sc_sim_topk")
+    return idx, score
+
+
+# ------------------------------------------------------------------------------------------------
+# dense blocks (MFMA GEMM + norms)
+# ------------------------------------------------------------------------------------------------
+EPI = {"none": 0, "quick_gelu": 1, "gelu": 2}
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual); fp16 operands, fp32 MFMA accumulate.
+    `a` may be a row-strided view (stride(1) == 1)."""
+    _require_cuda(a, w)
+    lib = _lib.load()
+    if a.dtype != torch.float16 or w.dtype != torch.float16:
+        raise StreamChatHipError("gemm: fp16 operands only")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K2 != K or a.stride(1) != 1 or not w.is_contiguous():
+        raise StreamChatHipError("gemm: shape/stride mismatch")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.float16, device=a.device)
+    if out.stride(1) != 1 or (residual is not None and residual.stride(1) != 1):
+        raise StreamChatHipError("gemm: out/residual must be row-major")
+    from ctypes import c_void_p
+    P = lambda t: None if t is None else c_void_p(t.data_ptr())
+    with torch.cuda.device(a.device):
+        check(lib.sc_gemm_f16(P(a), a.stride(0), P(w), P(bias), P(residual), 0 if residual is None else residual.stride(0), P(out),
+                              out.stride(0), M, N, K, EPI[epilogue], 1 if out.dtype == torch.float32 else 0, stream_ptr(a.device)),
+              "sc_gemm_f16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out=None):
+    _require_cuda(x, gamma, beta)
+    lib = _lib.load()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float16, device=x.device)
+    from ctypes import c_void_p
+    with torch.cuda.device(x.device):
+        check(lib.sc_layernorm_f16(c_void_p(x.data_ptr()), x.stride(0), ptr(gamma), ptr(beta), c_float(eps), c_void_p(out.data_ptr()),
+                                   out.stride(0), rows, cols, stream_ptr(x.device)), "sc_layernorm_f16")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
+    _require_cuda(x, gamma)
+    lib = _lib.load()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float16, device=x.device)
+    from ctypes import c_void_p
+    with torch.cuda.device(x.device):
+        check(lib.sc_rmsnorm_f16(c_void_p(x.data_ptr()), x.stride(0), ptr(gamma), c_float(eps), c_void_p(out.data_ptr()), out.stride(0),
+                                 rows, cols, stream_ptr(x.device)), "sc_rmsnorm_f16")
+    return out

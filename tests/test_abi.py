@@ -1,0 +1,43 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "streamchat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(hip_lib):
+    names = declared_symbols()
+    assert "sc_kmeans_fit" in names and "sc_abi_version" in names
+    raw = ctypes.CDLL(os.path.join(ROOT, "streamchat_amd", "libstreamchat_hip.so"))
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, f"declared in include/streamchat_hip.h but not exported: {missing}"
+
+
+def test_binding_covers_header(hip_lib):
+    from streamchat_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_abi_version_and_error_text(hip_lib):
+    assert hip_lib.sc_abi_version() == 1
+    # argument validation happens before any device work, so it is callable without a GPU
+    rc = hip_lib.sc_kmeans_fit(None, 0, 1, 8, 1, None, None, None, 0, 1, 1e-4, None, None, None, None, None, 0, None)
+    assert rc == -1
+    assert b"null pointer" in hip_lib.sc_last_error()
+    assert hip_lib.sc_kmeans_workspace_bytes(400, 576 * 3584, 5) > 0
+
+
+def test_no_cpu_fallback():
+    import pytest
+    import torch
+    from streamchat_amd import ops
+    from streamchat_amd._lib import StreamChatHipError
+    with pytest.raises(StreamChatHipError):
+        ops.kmeans_fit(torch.zeros(8, 16), 2, [0, 1])        # CPU tensor: refused, never computed on the host

@@ -1,0 +1,64 @@
+"""GPU: MFMA GEMM + norms through the C ABI against a plain PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+
+from streamchat_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).half()
+
+
+def test_gemm_transpose_detecting():
+    """A = I with an ASYMMETRIC W catches swapped rows/cols in the MFMA C/D mapping."""
+    K = N = 128
+    A = torch.eye(K, device="cuda").half()
+    W = (torch.arange(N * K, device="cuda").reshape(N, K) % 97).half()           # W[n,k] != W[k,n]
+    out = ops.gemm(A, W)
+    assert torch.equal(out, W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(577, 1024, 1024), (1, 128, 64), (130, 3072, 1024), (1154, 4096, 1024), (300, 1024, 4096),
+                                    (576, 1024, 640), (257, 384, 1536), (64, 3584, 3584)])
+@pytest.mark.parametrize("epi", ["none", "quick_gelu", "gelu"])
+def test_gemm_vs_torch_fp32(M, N, K, epi):
+    a, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    r = _rand((M, N), 4)
+    out = ops.gemm(a, w, b, r, epi)
+    ref = a.float() @ w.float().t() + b.float()
+    if epi == "quick_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    ref = ref + r.float()
+    # fp16 output rounding (2^-11 relative) + fp32 accumulation-order noise
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_gemm_strided_a_and_f32_out():
+    a_full = _rand((200, 3072), 5)
+    a = a_full[:, 1024:2048]                                                       # row-strided view, lda = 3072
+    w = _rand((256, 1024), 6, 1 / 32)
+    out = ops.gemm(a, w, out_f32=True)
+    torch.testing.assert_close(out, a.float() @ w.float().t(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_rejects_bad_shapes():
+    from streamchat_amd._lib import StreamChatHipError
+    with pytest.raises(StreamChatHipError):
+        ops.gemm(_rand((8, 100), 1), _rand((128, 100), 2))                        # K % 64 != 0 -> loud error, no fallback
+
+
+@pytest.mark.parametrize("rows,cols", [(577, 1024), (5, 384), (33, 3584), (1000, 4096), (7, 64)])
+def test_layernorm_rmsnorm(rows, cols):
+    x, g, b = _rand((rows, cols), 1, 3.0), _rand((cols,), 2), _rand((cols,), 3)
+    y = ops.layernorm(x, g, b, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.float(), (cols,), g.float(), b.float(), 1e-5)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+    y = ops.rmsnorm(x, g, 1e-6)
+    xf = x.float()
+    ref = g.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).half().float()
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)

@@ -1,0 +1,116 @@
+"""GPU: the HIP k-means (through the C ABI) against the oracle and the reference golden vectors."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from streamchat_amd import ops, utiles as U
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(G, "kmeans_0*.npz")))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_kmeans_matches_reference_golden(path):
+    d = np.load(path)
+    X = torch.from_numpy(d["X"]).cuda()
+    T, K = X.shape[0], int(d["K"])
+    w = torch.from_numpy(d["weights"]).cuda() if "weights" in d.files else None
+    C, labels, wsum, info = ops.kmeans_fit(X.reshape(T, -1), K, d["init_idx"], d["reseed_idx"], weights=w)
+    assert np.array_equal(labels.cpu().numpy(), d["labels"])                     # bit-exact assignments
+    assert int(info[0]) == int(d["exit_iter"]) and int(info[1]) == 0
+    np.testing.assert_allclose(C.cpu().numpy(), d["centroids"].reshape(K, -1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(wsum.cpu().numpy(), d["wsum"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T,D,K", [(40, 512 * 3, 5), (64, 1024 + 8, 8), (37, 520, 3), (50, 100, 4), (300, 2048, 16), (70, 4096, 20)])
+def test_kmeans_bit_exact_vs_oracle(dtype, T, D, K):
+    """labels AND centroids bit-identical to the oracle (shared SC-KM1 reduction spec), incl. unaligned D (100)
+    and K > 16 (two centroid tiles)."""
+    g = torch.Generator().manual_seed(T * 1000 + D + K)
+    centres = torch.randn(max(K - 1, 2), D, generator=g)
+    X = (centres[torch.randint(0, centres.shape[0], (T,), generator=g)] + 0.3 * torch.randn(T, D, generator=g)).to(dtype)
+    init = torch.randperm(T, generator=g)[:K].to(torch.int32)
+    reseed = torch.randint(0, T, (10 * K,), generator=g).to(torch.int32)
+    Xn = (X.view(torch.int16).numpy().view(np.uint16), "bfloat16") if dtype == torch.bfloat16 else X.numpy()
+    ref = oracle.kmeans_fit(Xn, K, init.numpy(), reseed.numpy())
+    C, labels, wsum, info = ops.kmeans_fit(X.cuda(), K, init, reseed)
+    assert np.array_equal(labels.cpu().numpy(), ref["labels"])
+    assert int(info[0]) == ref["iters"]
+    assert np.array_equal(C.cpu().numpy(), ref["centroids"])                      # bit-exact, not just close
+    assert np.array_equal(wsum.cpu().numpy(), ref["wsum"])
+
+
+def test_kmeans_assign_dist2_bit_exact():
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(45, 512 * 5 + 64, generator=g).half()
+    C = torch.randn(6, X.shape[1], generator=g)
+    labels, d2 = ops.kmeans_assign(X.cuda(), C.cuda(), return_dist2=True)
+    ref = oracle.kmeans_dist2(X.numpy(), C.numpy())
+    assert np.array_equal(d2.cpu().numpy(), ref)                                  # fp64 totals identical
+    assert np.array_equal(labels.cpu().numpy(), ref.argmin(1))
+
+
+def test_kmeans_exact_ties_pick_first():
+    X = torch.zeros(16, 512)
+    X[8:] = 1.0
+    C, labels, wsum, info = ops.kmeans_fit(X.cuda(), 3, [0, 1, 8], [3, 4, 5] * 10)   # centroids 0 and 1 identical
+    lab = labels.cpu().numpy()
+    assert set(lab[:8]) == {0} and set(lab[8:]) == {2}                            # first minimum wins; cluster 1 empty
+    assert int(info[2]) >= 1                                                      # a reseed was consumed
+
+
+def test_weighted_kmeans_feature_dropin_shapes():
+    d = np.load(CASES[0])
+    X = torch.from_numpy(d["X"]).cuda().half()
+    red, labels = U.weighted_kmeans_feature(X, int(d["K"]), init_idx=d["init_idx"], reseed_idx=d["reseed_idx"])
+    assert red.shape == (int(d["K"]),) + X.shape[1:] and red.dtype == torch.float16
+    assert labels.dtype == torch.int64 and np.array_equal(labels.cpu().numpy(), d["labels"])
+    small = U.weighted_kmeans_feature(X[:3], 5)
+    assert len(small) == 3
+
+
+def test_kmeans_full_width_properties():
+    """BASELINE C1-sized width (D = 576*3584) at a reduced row count: size-independent properties —
+    planted clusters are recovered, labels are invariant to a permutation of the columns' chunk order
+    is NOT assumed; instead: idempotence (re-fitting from the returned centroids converges at iter 0)."""
+    D, T, K = 576 * 3584, 24, 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    centres = torch.randn(K, D, device="cuda", generator=g, dtype=torch.float16)
+    which = torch.arange(T, device="cuda") % K
+    X = centres[which] + 0.05 * torch.randn(T, D, device="cuda", generator=g, dtype=torch.float16)
+    C, labels, wsum, info = ops.kmeans_fit(X, K, [0, 1, 2, 3], None)
+    assert torch.equal(labels, which)                                             # init rows 0..3 are one per cluster
+    assert torch.equal(wsum, torch.full((K,), T / K, device="cuda"))
+    lab2 = ops.kmeans_assign(X, C)
+    assert torch.equal(lab2, labels)
+    # centroid = mean of members (fp32 sequential sum): compare with torch at fp tolerance
+    for k in range(K):
+        ref = X[which == k].float().mean(0)
+        torch.testing.assert_close(C[k], ref, rtol=1e-5, atol=1e-5)
+
+
+def test_tree_trace_on_gpu():
+    """G5 trace through the real HIP k-means (device tensors)."""
+    from tests.test_host_logic import FakeSummarizer, FakeTok, describe
+    cases = json.load(open(os.path.join(G, "tree_trace.json")))
+    c = cases[0]
+    chunk, K, interval, P, D = c["chunk"], c["K"], c["interval"], c["P"], c["D"]
+    torch.manual_seed(100 + chunk)
+    summ, tok = FakeSummarizer(), FakeTok()
+    tree, gframe = None, 0
+    for upd in c["trace"]:
+        buf = []
+        for _ in range(c["frames_per_update"]):
+            buf.append((torch.full((1, P, D), float(gframe)) + 0.01 * torch.randn(1, P, D)).cuda()); gframe += 1
+        chunked = [buf[i:i + chunk] for i in range(0, len(buf), chunk)]
+        km = [torch.cat(x) for x in chunked]
+        tree = U.fast_building_memory_tree_summarize_token(km, K, interval, summ, torch.zeros(1, 3, dtype=torch.long), tok, chunked, tree)
+        got = describe(tree)
+        assert [(n["depth"], n["shape"], len(n["children"])) for n in got] == [(n["depth"], n["shape"], len(n["children"])) for n in upd["top"]]
