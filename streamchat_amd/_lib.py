@@ -29,6 +29,8 @@ SIGNATURES = {
     "sc_gemm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_layernorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_rmsnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sc_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_float, c_int, c_void_p, c_void_p]),
     "sc_sim_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -1,0 +1,260 @@
+// Fused multi-head attention for gfx950 (CDNA4), fp16 in/out, fp32 online softmax.
+//   ViT-L: S = 577, 16 heads x 64, non-causal  (HF CLIPAttention behind reference clip_encoder.py:76)
+//   BERT : padding-masked (kv_len), 12..16 heads x 32/64 (reference utiles.py:707,728)
+//   Qwen2: causal GQA 28/4 heads x 128 over 26k-49k stacked frame tokens (reference llava_qwen.py:155)
+//
+// Orientation: everything is computed TRANSPOSED so that one lane owns one query column end to end.
+//   S^T[kv][q] = K[kv][:] . Q[q][:]      A = K fragment (LDS, ds_read_b128),  B = Q fragment (registers)
+//   O^T[d][q] += V^T[d][kv] . P^T[kv][q]  A = V^T fragment (row-major V tile in LDS read with
+//                                          ds_read_b64_tr_b16, the gfx950 transpose read), B = P^T (registers)
+// With v_mfma_f32_16x16x32_f16 the C/D layout is col = lane&15, row = (lane>>4)*4 + r, so the P values a lane
+// produced for its query column are exactly the B-operand k-slots it must feed to the second MFMA (the
+// k-slot <-> kv-row bijection is applied to the V rows the transpose read fetches).  Row max / row sum /
+// rescale factors are therefore per-lane scalars: no LDS round trip and no cross-lane traffic for P; only a
+// 2-step xor-shuffle for the row max across the 4 lane groups.
+//
+// Block = 4 waves x QB q-blocks of 16 queries; KV tiles of 64 rows double-buffered in LDS via 16-byte
+// global_load_lds; bank-conflict-free XOR swizzles are applied on the per-lane source address and on the reads.
+#include "sc_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef short sc_s4 __attribute__((ext_vector_type(4)));
+
+constexpr int KVT = 64;   // kv rows per tile
+
+template <int DH, int QB, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+                                              const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
+                                              int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = KVT * DH * 2;            // bytes per K (or V) tile
+    constexpr int STAGE = 2 * TILE;
+    constexpr int GPT = TILE / 16 / 256;          // 16-byte granules per thread per operand tile (2 or 4)
+    constexpr int DS = DH / 32;                   // MFMA k-steps over the head dim
+    constexpr int DB = DH / 16;                   // 16-row blocks of O^T
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (Hq / Hkv);
+    const int qblk0 = blockIdx.x * (4 * QB * 16);
+    const int qw0 = qblk0 + wave * (QB * 16);
+    const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
+    const int coff = Skv - Sq;                    // causal: query i sits at kv position i + coff
+
+    int nt = (kv_valid + KVT - 1) / KVT;
+    if (CAUSAL) {
+        const int last_q = min(qblk0 + 4 * QB * 16, Sq) - 1;
+        const int lim = (last_q + coff) / KVT + 1;
+        nt = nt < lim ? nt : lim;
+    }
+
+    // ---- Q fragments (registers, loaded once) ----
+    sc_h8 qf[QB][DS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qr = qw0 + qb * 16 + rl;
+        qr = qr < Sq ? qr : Sq - 1;
+        const _Float16* qp = Q + ((size_t)b * Sq + qr) * (size_t)ldq + h * DH + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+    }
+
+    // ---- staging sources ----
+    const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
+    const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
+    int k_r[GPT], k_s[GPT], v_r[GPT], v_s[GPT];
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int q = j * 256 + tid;
+        if (DH == 64) {
+            k_r[j] = 2 * (q >> 4) + ((q & 15) >> 3);
+            k_s[j] = (q & 7) ^ ((q >> 4) & 7);
+            v_r[j] = q >> 3;
+            v_s[j] = (q & 7) ^ (((v_r[j] >> 1) & 3) << 1);
+        } else {
+            k_r[j] = q >> 4;
+            k_s[j] = (q & 15) ^ (k_r[j] & 15);
+            v_r[j] = q >> 4;
+            v_s[j] = (q & 15) ^ ((v_r[j] & 7) << 1);
+        }
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * STAGE;
+        const int kv0 = t * KVT;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            int kr = kv0 + k_r[j]; kr = kr < Skv ? kr : Skv - 1;
+            int vr = kv0 + v_r[j]; vr = vr < Skv ? vr : Skv - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kbase + (size_t)kr * (size_t)ldk + k_s[j] * 8),
+                                             (lds_ptr_t)(base + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (size_t)vr * (size_t)ldv + v_s[j] * 8),
+                                             (lds_ptr_t)(base + TILE + (j * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- read addresses ----
+    int k_off[DS];   // K fragment byte offset of (row rl, d-step ds) inside a 16-row block
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+        if (DH == 64) k_off[ds] = (rl >> 1) * 256 + ((((rl & 1) << 3) | ((ds * 4 + g) ^ ((rl >> 1) & 7))) << 4);
+        else k_off[ds] = rl * 256 + (((ds * 4 + g) ^ rl) << 4);
+    }
+    constexpr int KBLK = 16 * DH * 2;             // bytes per 16 kv rows
+    // V transpose-read: this lane supplies row (4g + (rl>>2)) [+16 for the second read] of a 32-row chunk,
+    // 8-byte column chunk (rl&3) of the 16-column d-block db
+    const int vrow = 4 * g + (rl >> 2);
+    int v_off[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        if (DH == 64) v_off[db] = vrow * 128 + ((db ^ ((vrow >> 1) & 3)) << 5) + (rl & 3) * 8;
+        else v_off[db] = vrow * 256 + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+    }
+    constexpr int VROW = DH * 2;
+
+    sc_f4 o[DB][QB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int j = 0; j < QB; ++j) o[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+
+    if (nt > 0) stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+        const char* sk = smem + cur * STAGE;
+        const char* sv = sk + TILE;
+
+        // ---- S^T = K . Q^T ----
+        sc_f4 s[4][QB];
+#pragma unroll
+        for (int kvb = 0; kvb < 4; ++kvb) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) s[kvb][qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                const sc_h8 kf = *reinterpret_cast<const sc_h8*>(sk + kvb * KBLK + k_off[ds]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ds], s[kvb][qb], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (per lane = per query column) ----
+        sc_h8 pf[QB][2];
+        const int kv_t0 = t * KVT + g * 4;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qpos = qw0 + qb * 16 + rl + coff;
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kvb = 0; kvb < 4; ++kvb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = kv_t0 + kvb * 16 + r;
+                    float x = s[kvb][qb][r] * scale_log2;
+                    const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                    x = dead ? -INFINITY : x;
+                    s[kvb][qb][r] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qb], tmax);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kvb = 0; kvb < 4; ++kvb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kvb][qb][r] - m_use);
+                    psum += p;
+                    pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p;
+                }
+            l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                o[db][qb][0] *= alpha; o[db][qb][1] *= alpha; o[db][qb][2] *= alpha; o[db][qb][3] *= alpha;
+            }
+        }
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const char* vp = sv + c * 32 * VROW + v_off[db];
+                const sc_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp));
+                const sc_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp + 16 * VROW));
+                typedef short sc_s8 __attribute__((ext_vector_type(8)));
+                const sc_s8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const sc_h8 vf = __builtin_bit_cast(sc_h8, v8);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][c], o[db][qb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qr = qw0 + qb * 16 + rl;
+        if (qr < Sq) {
+            _Float16* op = O + ((size_t)b * Sq + qr) * (size_t)ldo + h * DH + g * 4;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const sc_h4 v = {(_Float16)(o[db][qb][0] * inv), (_Float16)(o[db][qb][1] * inv), (_Float16)(o[db][qb][2] * inv),
+                                 (_Float16)(o[db][qb][3] * inv)};
+                *reinterpret_cast<sc_h4*>(op + db * 16) = v;
+            }
+        }
+    }
+}
+
+template <int DH, int QB>
+int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, hipStream_t s) {
+    const dim3 grid((unsigned)((Sq + 4 * QB * 16 - 1) / (4 * QB * 16)), (unsigned)Hq, (unsigned)B), block(256);
+    const size_t lds = 2 * 2 * KVT * DH * 2;
+    const float sl2 = scale * 1.4426950408889634f;
+    if (causal)
+        hipLaunchKernelGGL((k_attn<DH, QB, true>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len);
+    else
+        hipLaunchKernelGGL((k_attn<DH, QB, false>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len);
+    SC_CHECK_LAUNCH("sc_attention_f16");
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
+                                int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
+                                sc_stream_t stream) {
+    SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
+    SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
+    SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
+    SC_REQUIRE(!causal || Skv >= Sq, "sc_attention_f16: causal needs Skv >= Sq");
+    SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sc_attention_f16: leading dims must be multiples of 8 (out: 4)");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(out) & 7) == 0, "sc_attention_f16: q/k/v must be 16-byte aligned, out 8-byte");
+    SC_REQUIRE(B <= 65535 && Hq <= 65535, "sc_attention_f16: B and Hq must be <= 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
+    return sc_fail(SC_ERR_UNSUPPORTED, "sc_attention_f16: head dim 32 not built yet");
+}

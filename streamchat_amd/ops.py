@@ -204,3 +204,24 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
         check(lib.sc_rmsnorm_f16(c_void_p(x.data_ptr()), x.stride(0), ptr(gamma), c_float(eps), c_void_p(out.data_ptr()), out.stride(0),
                                  rows, cols, stream_ptr(x.device)), "sc_rmsnorm_f16")
     return out
+
+
+def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None):
+    """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused
+    QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh]."""
+    _require_cuda(q, k, v)
+    lib = _lib.load()
+    B, Sq = q.shape[0], q.shape[1]
+    Skv = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise StreamChatHipError("attention: tensors must be [B, S, *] with dense batch stride and unit last stride")
+    if out is None:
+        out = torch.empty((B, Sq, Hq * Dh), dtype=torch.float16, device=q.device)
+    from ctypes import c_void_p
+    P = lambda t: None if t is None else c_void_p(t.data_ptr())
+    kl = None if kv_len is None else kv_len.to(device=q.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(q.device):
+        check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), out.stride(1), B, Sq, Skv, Hq, Hkv, Dh,
+                                   c_float(scale), 1 if causal else 0, P(kl), stream_ptr(q.device)), "sc_attention_f16")
+    return out

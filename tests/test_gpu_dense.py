@@ -62,3 +62,53 @@ def test_layernorm_rmsnorm(rows, cols):
     xf = x.float()
     ref = g.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).half().float()
     torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def _attn_ref(q, k, v, Hq, Hkv, Dh, scale, causal, kv_len=None):
+    B, Sq, _ = q.shape
+    Skv = k.shape[1]
+    qf = q.float().view(B, Sq, Hq, Dh).transpose(1, 2)
+    kf = k.float().view(B, Skv, Hkv, Dh).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    vf = v.float().view(B, Skv, Hkv, Dh).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Sq, device=q.device)[:, None] + (Skv - Sq)
+        j = torch.arange(Skv, device=q.device)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    if kv_len is not None:
+        j = torch.arange(Skv, device=q.device)[None, None, None, :]
+        s = s.masked_fill(j >= kv_len.view(B, 1, 1, 1), float("-inf"))
+    return (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, Sq, Hq * Dh)
+
+
+@pytest.mark.parametrize("B,Sq,Skv,Hq,Hkv,Dh,causal", [
+    (3, 577, 577, 16, 16, 64, False),       # ViT-L block
+    (2, 64, 64, 2, 2, 64, False), (1, 1, 130, 4, 4, 64, False), (2, 100, 100, 4, 4, 64, True),
+    (1, 300, 300, 28, 4, 128, True),        # Qwen2 GQA prefill
+    (1, 17, 200, 8, 2, 128, True),          # chunked prefill: queries aligned to the end of the keys
+    (2, 129, 129, 4, 4, 128, False)])
+def test_attention_vs_torch_fp32(B, Sq, Skv, Hq, Hkv, Dh, causal):
+    q, k, v = _rand((B, Sq, Hq * Dh), 1), _rand((B, Skv, Hkv * Dh), 2), _rand((B, Skv, Hkv * Dh), 3)
+    out = ops.attention(q, k, v, Hq, Hkv, Dh, Dh ** -0.5, causal)
+    ref = _attn_ref(q, k, v, Hq, Hkv, Dh, Dh ** -0.5, causal)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_attention_fused_qkv_views_and_padding_mask():
+    B, S, H, Dh = 3, 50, 4, 64
+    qkv = _rand((B, S, 3 * H * Dh), 7)
+    q, k, v = qkv[..., : H * Dh], qkv[..., H * Dh: 2 * H * Dh], qkv[..., 2 * H * Dh:]
+    kv_len = torch.tensor([50, 7, 33], device="cuda", dtype=torch.int32)
+    out = ops.attention(q, k, v, H, H, Dh, 0.125, False, kv_len)
+    ref = _attn_ref(q, k, v, H, H, Dh, 0.125, False, kv_len)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """One key spikes against every query late in the sequence so the running max jumps (guide rule 26)."""
+    B, S, H, Dh = 1, 256, 2, 64
+    q, k, v = _rand((B, S, H * Dh), 1), _rand((B, S, H * Dh), 2), _rand((B, S, H * Dh), 3)
+    k[0, 200] = q[0, 10] * 4                      # large q.k for kv row 200 (4th tile)
+    out = ops.attention(q, k, v, H, H, Dh, 0.125, False)
+    ref = _attn_ref(q, k, v, H, H, Dh, 0.125, False)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
