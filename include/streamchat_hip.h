@@ -86,6 +86,11 @@ int sc_preprocess_u8(const uint8_t* hwc, int n, int h, int w, const float* mean,
 int sc_preprocess_patchify_u8(const uint8_t* hwc, int n, int h, int w, int patch, const float* mean,
                               const float* std, void* out_f16, int ld, sc_stream_t stream);
 
+/* Patch gather for already-normalised fp16 pixel values [n, 3, h, w] (the tensor the reference hands to
+ * `encode_images`, llava_arch.py:179): same output layout as sc_preprocess_patchify_u8. */
+int sc_patchify_f16(const void* chw_f16, int n, int h, int w, int patch, void* out_f16, int ld,
+                    sc_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Similarity top-k.  Replaces `cos_sim` + strict-> running argmax of the tree search
  * (reference utiles.py:732,738-740,768-771) and the FAISS flat-L2 `similarity_search_with_score`
@@ -106,9 +111,18 @@ enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2 };
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N]).  fp16 in, fp32 accumulate (MFMA),
  * fp16 out (out_f32 = 0) or fp32 out (out_f32 = 1).  W has the torch.nn.Linear layout [N, K].
  * lda / ldr / ldc in elements.  Requirements: K % 64 == 0, N % 128 == 0, A and W 16-byte aligned,
- * lda % 8 == 0.  M is arbitrary.  bias and residual may be NULL. */
+ * lda % 8 == 0.  M is arbitrary.  bias and residual may be NULL.
+ * Optional A row-group map (a_grp > 0): logical row m reads storage row
+ * (m / a_grp) * a_grp_stride + a_grp_off + m % a_grp  — e.g. (576, 577, 1) drops the CLS token of every
+ * frame (`feature_select`, reference clip_encoder.py:46-66) without a copy. */
 int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const void* residual, int ldr,
-                void* C, int ldc, int M, int N, int K, int epilogue, int out_f32, sc_stream_t stream);
+                void* C, int ldc, int M, int N, int K, int epilogue, int out_f32, int a_grp,
+                int a_grp_stride, int a_grp_off, sc_stream_t stream);
+/* ViT token assembly + pre-LayerNorm (HF CLIPVisionEmbeddings + pre_layrnorm):
+ *   out[n, 0]     = LN(cls + pos[0]);  out[n, 1 + p] = LN(patch[n*P + p] + pos[1 + p])
+ * patch [N*P, D], cls [D], pos [P+1, D], out [N*(P+1), D], all fp16; D % 8 == 0, D <= 4096. */
+int sc_vit_embed_ln_f16(const void* patch, const void* cls, const void* pos, const void* gamma,
+                        const void* beta, float eps, void* out, int N, int P, int D, sc_stream_t stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim, fp32 statistics; [rows, cols] fp16, cols % 8 == 0,
  * cols <= 4096. */
 int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y,

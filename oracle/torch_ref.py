@@ -1,0 +1,68 @@
+"""TEST INFRASTRUCTURE — plain PyTorch fp32 restatement of the third-party arithmetic the reference calls.
+
+The ViT / projector / BERT / Qwen2 math is NOT under /root/reference: it lives in transformers==4.37.2
+(requirements.txt:149) behind the call sites clip_encoder.py:41,76 (CLIPVisionModel), multimodal_projector/
+builder.py:41-48 (nn.Sequential), utiles.py:707,728 (AutoModel -> BertModel) and llava_qwen.py:29,46,155
+(Qwen2ForCausalLM).  These functions restate the published algorithms with explicit state-dict weights (HF
+parameter names) and are pinned against the installed transformers (5.15.0) modules by the golden fixtures
+tests/golden/clip_tiny.npz, bert_tiny.npz, qwen2_tiny.npz (tools/make_golden_hf.py).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _mha(x, sd, pre, heads, mask=None, causal=False):
+    B, S, D = x.shape
+    dh = D // heads
+    q = F.linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
+    k = F.linear(x, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
+    v = F.linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    if mask is not None:
+        s = s + mask
+    a = torch.softmax(s, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, S, D)
+    return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+
+
+def clip_vision_hidden(sd, pixel_values, *, heads, patch, layers_run, eps=1e-5, prefix="vision_model."):
+    """hidden state after `layers_run` encoder layers (HF hidden_states[layers_run]); [N, 1+P, D] fp32.
+    HF CLIPVisionTransformer: patch Conv2d(no bias) -> [cls | patches] + position embedding -> pre_layrnorm ->
+    layers of (LN1, MHA, +res, LN2, fc1, quick_gelu, fc2, +res)."""
+    p = prefix
+    w = sd[p + "embeddings.patch_embedding.weight"]
+    x = F.conv2d(pixel_values, w, stride=patch)                        # [N, D, gh, gw]
+    N, D = x.shape[0], x.shape[1]
+    x = x.flatten(2).transpose(1, 2)                                   # [N, P, D]
+    cls = sd[p + "embeddings.class_embedding"].expand(N, 1, D)
+    x = torch.cat([cls, x], dim=1) + sd[p + "embeddings.position_embedding.weight"][None]
+    x = _ln(x, sd[p + "pre_layrnorm.weight"], sd[p + "pre_layrnorm.bias"], eps)
+    for i in range(layers_run):
+        lp = f"{p}encoder.layers.{i}."
+        h = _ln(x, sd[lp + "layer_norm1.weight"], sd[lp + "layer_norm1.bias"], eps)
+        x = x + _mha(h, sd, lp + "self_attn.", heads)
+        h = _ln(x, sd[lp + "layer_norm2.weight"], sd[lp + "layer_norm2.bias"], eps)
+        h = F.linear(h, sd[lp + "mlp.fc1.weight"], sd[lp + "mlp.fc1.bias"])
+        h = h * torch.sigmoid(1.702 * h)                               # quick_gelu
+        x = x + F.linear(h, sd[lp + "mlp.fc2.weight"], sd[lp + "mlp.fc2.bias"])
+    return x
+
+
+def mm_projector(sd, x, prefix=""):
+    """mlp2x_gelu (reference multimodal_projector/builder.py:41-48): Linear -> GELU(erf) -> Linear; keys 0.* / 2.*"""
+    h = F.gelu(F.linear(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"]))
+    return F.linear(h, sd[prefix + "2.weight"], sd[prefix + "2.bias"])
+
+
+def encode_images(sd_vit, sd_proj, pixel_values, *, heads, patch, num_layers, select_layer=-2):
+    """reference llava_arch.py:179-184 + clip_encoder.py:46-79: hidden_states[select_layer][:, 1:] -> projector.
+    hidden_states has num_layers+1 entries, so index -2 is the output of layer num_layers-1."""
+    run = num_layers + 1 + select_layer if select_layer < 0 else select_layer
+    h = clip_vision_hidden(sd_vit, pixel_values, heads=heads, patch=patch, layers_run=run)
+    return mm_projector(sd_proj, h[:, 1:])

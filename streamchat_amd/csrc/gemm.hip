@@ -35,7 +35,8 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                     const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
-                                                    void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN) {
+                                                    void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
+                                                    int a_grp_stride, int a_grp_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- XCD-aware, bijective block remap (block b runs on XCD b % 8) ----
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
     for (int i = 0; i < 4; ++i) {
         int ar = tm * BM + i * 32 + srow;
         ar = ar < M ? ar : M - 1;                       // rows past M re-read the last row (never stored)
+        if (a_grp > 0) ar = (ar / a_grp) * a_grp_stride + a_grp_off + (ar % a_grp);   // logical row -> storage row
         a_src[i] = A + (size_t)ar * (size_t)lda + sslot * 8;
         w_src[i] = W + (size_t)(tn * BN + i * 32 + srow) * (size_t)K + sslot * 8;
     }
@@ -142,16 +144,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
 
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
-                int K, int out_f32, hipStream_t s) {
+                int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
     const int tilesM = (M + BM - 1) / BM, tilesN = N / BN;
     const dim3 grid((unsigned)(tilesM * tilesN)), block(256);
     const size_t lds = 2 * STAGE_BYTES;
     if (out_f32)
         hipLaunchKernelGGL((k_gemm128<EPI, true>), grid, block, lds, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                           (const _Float16*)R, ldr, C, ldc, M, N, K, tilesN);
+                           (const _Float16*)R, ldr, C, ldc, M, N, K, tilesN, a_grp, a_grp_stride, a_grp_off);
     else
         hipLaunchKernelGGL((k_gemm128<EPI, false>), grid, block, lds, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                           (const _Float16*)R, ldr, C, ldc, M, N, K, tilesN);
+                           (const _Float16*)R, ldr, C, ldc, M, N, K, tilesN, a_grp, a_grp_stride, a_grp_off);
     SC_CHECK_LAUNCH("sc_gemm_f16");
     return SC_OK;
 }
@@ -159,7 +161,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
 }  // namespace
 
 extern "C" int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const void* residual, int ldr, void* C, int ldc,
-                           int M, int N, int K, int epilogue, int out_f32, sc_stream_t stream) {
+                           int M, int N, int K, int epilogue, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, sc_stream_t stream) {
     SC_REQUIRE(A && W && C, "sc_gemm_f16: null pointer argument");
     SC_REQUIRE(M > 0 && N > 0 && K > 0, "sc_gemm_f16: M, N, K must be positive");
     SC_REQUIRE(N % BN == 0, "sc_gemm_f16: N (%d) must be a multiple of %d", N, BN);
@@ -169,11 +171,12 @@ extern "C" int sc_gemm_f16(const void* A, int lda, const void* W, const void* bi
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0, "sc_gemm_f16: A and W must be 16-byte aligned");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0,
                "sc_gemm_f16: C, bias, residual must be 8-byte aligned");
+    SC_REQUIRE(a_grp >= 0 && (a_grp == 0 || (a_grp_stride >= a_grp && a_grp_off >= 0)), "sc_gemm_f16: bad A row-group map");
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case SC_EPI_NONE: return launch_gemm<SC_EPI_NONE>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, s);
-        case SC_EPI_QUICK_GELU: return launch_gemm<SC_EPI_QUICK_GELU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, s);
-        case SC_EPI_GELU_ERF: return launch_gemm<SC_EPI_GELU_ERF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, s);
+        case SC_EPI_NONE: return launch_gemm<SC_EPI_NONE>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
+        case SC_EPI_QUICK_GELU: return launch_gemm<SC_EPI_QUICK_GELU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
+        case SC_EPI_GELU_ERF: return launch_gemm<SC_EPI_GELU_ERF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
     }
     return sc_fail(SC_ERR_ARG, "sc_gemm_f16: unknown epilogue %d", epilogue);
 }

@@ -73,6 +73,61 @@ __global__ __launch_bounds__(256) void k_norm(const _Float16* __restrict__ x, in
     }
 }
 
+// ViT token assembly + pre-LN: one wave per output token
+template <int NV>
+__global__ __launch_bounds__(256) void k_vit_embed_ln(const _Float16* __restrict__ patch, const _Float16* __restrict__ cls,
+                                                      const _Float16* __restrict__ pos, const _Float16* __restrict__ gamma,
+                                                      const _Float16* __restrict__ beta, float eps, _Float16* __restrict__ out, int rows,
+                                                      int P, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n = row / (P + 1), tkn = row - n * (P + 1);
+    const _Float16* src = tkn == 0 ? cls : patch + ((size_t)n * P + (tkn - 1)) * (size_t)D;
+    const _Float16* pr = pos + (size_t)tkn * D;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < D) {
+            const sc_h8 a = *reinterpret_cast<const sc_h8*>(src + c);
+            const sc_h8 b = *reinterpret_cast<const sc_h8*>(pr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)(_Float16)(a[e] + b[e]); s += v[i][e]; }   // fp16 add like HF (fp16 embeddings)
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)D + eps);
+    _Float16* yr = out + (size_t)row * (size_t)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < D) {
+            const sc_h8 g = *reinterpret_cast<const sc_h8*>(gamma + c);
+            const sc_h8 b = *reinterpret_cast<const sc_h8*>(beta + c);
+            sc_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            *reinterpret_cast<sc_h8*>(yr + c) = o;
+        }
+    }
+}
+
 template <bool RMS>
 int launch_norm(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y, int ldy, int rows, int cols,
                 hipStream_t s, const char* name) {
@@ -113,4 +168,20 @@ extern "C" int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float e
                               sc_stream_t stream) {
     if (int rc = check_norm_args(x, ldx, gamma, y, ldy, rows, cols, "sc_rmsnorm_f16")) return rc;
     return launch_norm<true>(x, ldx, gamma, nullptr, eps, y, ldy, rows, cols, (hipStream_t)stream, "sc_rmsnorm_f16");
+}
+
+extern "C" int sc_vit_embed_ln_f16(const void* patch, const void* cls, const void* pos, const void* gamma, const void* beta, float eps,
+                                   void* out, int N, int P, int D, sc_stream_t stream) {
+    SC_REQUIRE(patch && cls && pos && gamma && beta && out, "sc_vit_embed_ln_f16: null pointer argument");
+    SC_REQUIRE(N > 0 && P > 0 && D > 0 && D % 8 == 0 && D <= 4096, "sc_vit_embed_ln_f16: need N, P > 0 and D a multiple of 8, <= 4096");
+    const int rows = N * (P + 1);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nv = (D + 511) / 512;
+    hipStream_t s = (hipStream_t)stream;
+#define SC_EMB(NV) hipLaunchKernelGGL((k_vit_embed_ln<NV>), grid, block, 0, s, (const _Float16*)patch, (const _Float16*)cls, (const _Float16*)pos, \
+                                      (const _Float16*)gamma, (const _Float16*)beta, eps, (_Float16*)out, rows, P, D)
+    if (nv <= 1) SC_EMB(1); else if (nv <= 2) SC_EMB(2); else if (nv <= 4) SC_EMB(4); else SC_EMB(8);
+#undef SC_EMB
+    SC_CHECK_LAUNCH("sc_vit_embed_ln_f16");
+    return SC_OK;
 }

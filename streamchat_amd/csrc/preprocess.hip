@@ -80,6 +80,36 @@ __global__ __launch_bounds__(256) void k_pre_patch(const uint8_t* __restrict__ i
     }
 }
 
+// fp16 CHW pixel values (the reference's `encode_images` input, llava_arch.py:179) -> patch rows
+__global__ __launch_bounds__(256) void k_patchify_f16(const _Float16* __restrict__ in, _Float16* __restrict__ out, size_t n_img, int h, int w,
+                                                      int P, int ld) {
+    const int gw = w / P, gh = h / P, kcols = 3 * P * P;
+    const size_t rows = n_img * (size_t)gh * gw;
+    const int gpr = ld / 8;
+    const size_t total = rows * (size_t)gpr;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = g / gpr;
+        const int c0 = (int)(g - row * gpr) * 8;
+        const size_t img = row / ((size_t)gh * gw);
+        const int pr = (int)(row - img * (size_t)gh * gw);
+        const int py = pr / gw, px = pr - py * gw;
+        sc_h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = c0 + e;
+            _Float16 r = (_Float16)0.f;
+            if (col < kcols) {
+                const int c = col / (P * P);
+                const int rem = col - c * P * P;
+                const int iy = rem / P, ix = rem - iy * P;
+                r = in[((img * 3 + c) * (size_t)h + (size_t)(py * P + iy)) * (size_t)w + (size_t)(px * P + ix)];
+            }
+            v[e] = r;
+        }
+        *reinterpret_cast<sc_h8*>(out + row * (size_t)ld + c0) = v;
+    }
+}
+
 Lut3 make_lut(const float* mean, const float* std) {
     Lut3 l;
     for (int c = 0; c < 3; ++c)
@@ -117,5 +147,18 @@ extern "C" int sc_preprocess_patchify_u8(const uint8_t* hwc, int n, int h, int w
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(k_pre_patch, dim3(grid), dim3(256), 0, (hipStream_t)stream, hwc, (_Float16*)out_f16, (size_t)n, h, w, patch, ld, nm);
     SC_CHECK_LAUNCH("sc_preprocess_patchify_u8");
+    return SC_OK;
+}
+
+extern "C" int sc_patchify_f16(const void* chw_f16, int n, int h, int w, int patch, void* out_f16, int ld, sc_stream_t stream) {
+    SC_REQUIRE(chw_f16 && out_f16, "sc_patchify_f16: null pointer argument");
+    SC_REQUIRE(n > 0 && h > 0 && w > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "sc_patchify_f16: bad sizes");
+    SC_REQUIRE(ld >= 3 * patch * patch && ld % 8 == 0, "sc_patchify_f16: ld must be >= 3*patch^2 and a multiple of 8");
+    SC_REQUIRE((reinterpret_cast<uintptr_t>(out_f16) & 15) == 0, "sc_patchify_f16: out must be 16-byte aligned");
+    const size_t total = (size_t)n * (h / patch) * (w / patch) * (ld / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_patchify_f16, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)chw_f16, (_Float16*)out_f16, (size_t)n, h, w,
+                       patch, ld);
+    SC_CHECK_LAUNCH("sc_patchify_f16");
     return SC_OK;
 }

@@ -156,14 +156,17 @@ def sim_topk(q: torch.Tensor, docs: torch.Tensor, k: int = 1, metric: str = "cos
 EPI = {"none": 0, "quick_gelu": 1, "gelu": 2}
 
 
-def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False):
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False,
+         a_rows=None, M=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual); fp16 operands, fp32 MFMA accumulate.
-    `a` may be a row-strided view (stride(1) == 1)."""
+    `a` may be a row-strided view (stride(1) == 1).  a_rows=(grp, stride, off) with explicit M reads logical
+    row m from storage row (m//grp)*stride + off + m%grp."""
     _require_cuda(a, w)
     lib = _lib.load()
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise StreamChatHipError("gemm: fp16 operands only")
-    M, K = a.shape
+    K = a.shape[1]
+    M = a.shape[0] if M is None else M
     N, K2 = w.shape
     if K2 != K or a.stride(1) != 1 or not w.is_contiguous():
         raise StreamChatHipError("gemm: shape/stride mismatch")
@@ -175,7 +178,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
     with torch.cuda.device(a.device):
         check(lib.sc_gemm_f16(P(a), a.stride(0), P(w), P(bias), P(residual), 0 if residual is None else residual.stride(0), P(out),
-                              out.stride(0), M, N, K, EPI[epilogue], 1 if out.dtype == torch.float32 else 0, stream_ptr(a.device)),
+                              out.stride(0), M, N, K, EPI[epilogue], 1 if out.dtype == torch.float32 else 0,
+                              *((0, 0, 0) if a_rows is None else a_rows), stream_ptr(a.device)),
               "sc_gemm_f16")
     return out
 
@@ -224,4 +228,33 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
     with torch.cuda.device(q.device):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), out.stride(1), B, Sq, Skv, Hq, Hkv, Dh,
                                    c_float(scale), 1 if causal else 0, P(kl), stream_ptr(q.device)), "sc_attention_f16")
+    return out
+
+
+def vit_embed_ln(patch, cls, pos, gamma, beta, eps: float, N: int, P: int, out=None):
+    """[N*P, D] patch embeddings -> [N*(P+1), D] tokens: (cls | patches) + position embedding, then pre-LayerNorm."""
+    _require_cuda(patch, cls, pos, gamma, beta)
+    lib = _lib.load()
+    D = patch.shape[1]
+    if out is None:
+        out = torch.empty((N * (P + 1), D), dtype=torch.float16, device=patch.device)
+    with torch.cuda.device(patch.device):
+        check(lib.sc_vit_embed_ln_f16(ptr(patch), ptr(cls), ptr(pos), ptr(gamma), ptr(beta), c_float(eps), ptr(out), N, P, D,
+                                      stream_ptr(patch.device)), "sc_vit_embed_ln_f16")
+    return out
+
+
+def patchify_f16(pixel_values: torch.Tensor, patch: int, ld: int, out=None) -> torch.Tensor:
+    """fp16 [N, 3, H, W] -> patch rows [N*(H/p)*(W/p), ld] (im2col order c,py,px; zero padded)."""
+    _require_cuda(pixel_values)
+    lib = _lib.load()
+    x = pixel_values.contiguous()
+    if x.dtype != torch.float16:
+        raise StreamChatHipError("patchify_f16: fp16 pixel values expected")
+    n, _, h, w = x.shape
+    rows = n * (h // patch) * (w // patch)
+    if out is None:
+        out = torch.empty((rows, ld), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.sc_patchify_f16(ptr(x), n, h, w, patch, ptr(out), ld, stream_ptr(x.device)), "sc_patchify_f16")
     return out

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Golden vectors for the THIRD-PARTY arithmetic (transformers) the reference calls — authoring container only.
+
+The installed transformers (5.15.0; the reference pins 4.37.2) provides CLIPVisionModel, BertModel and
+Qwen2ForCausalLM on CPU.  Tiny random-init configs are run in fp32 and their weights + inputs + outputs are
+saved, so oracle/torch_ref.py (and through it the HIP kernels) are pinned to the real HF modules at the call
+sites reference clip_encoder.py:76 (output_hidden_states, select layer -2, drop CLS), multimodal_projector/
+builder.py:41-48, utiles.py:707 (BertModel CLS) and llava_qwen.py:155."""
+import os
+import sys
+
+import numpy as np
+import torch
+import transformers
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def gen_clip():
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=56,
+                           patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=64)
+    m = CLIPVisionModel(cfg).eval()
+    with torch.no_grad():   # spread the (tiny-init) weights so the test is sensitive
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn_like(p) * (0.5 / p.shape[-1] ** 0.5) if "embedding" not in n else torch.randn_like(p) * 0.3)
+            else:
+                p.copy_(torch.randn_like(p) * 0.2 + (1.0 if "layer_norm" in n or "layrnorm" in n and n.endswith("weight") else 0.0))
+    proj = torch.nn.Sequential(torch.nn.Linear(128, 256), torch.nn.GELU(), torch.nn.Linear(256, 256)).eval()
+    x = torch.randn(3, 3, 56, 56)
+    with torch.no_grad():
+        out = m(x, output_hidden_states=True)
+        feat = out.hidden_states[-2][:, 1:]
+        y = proj(feat)
+    d = {"cfg_heads": 2, "cfg_patch": 14, "cfg_layers": 3, "pixel_values": x.numpy(), "features": feat.numpy(), "projected": y.numpy()}
+    for k, v in m.state_dict().items():   # store under the transformers-4.37.2 key names (vision_model.* prefix)
+        d["vit." + (k if k.startswith("vision_model.") else "vision_model." + k)] = v.numpy()
+    for k, v in proj.state_dict().items():
+        d["proj." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "clip_tiny.npz"), **d)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir("/root/reference"):
+        sys.exit("authoring container only")
+    torch.set_num_threads(1)
+    gen_clip()
+    print("transformers", transformers.__version__, "-> clip_tiny.npz")
