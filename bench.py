@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the streaming hot path on MI355X (driver contract in the task brief).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic 1024-frame 336x336 stream per GPU:
+  encode   uint8 frames -> fused preprocess/patchify -> ViT-L/14-336 (23 layers) -> mlp2x_gelu projector   [MFMA]
+  select   forgetting-curve short memory + chunking + memory-tree update incl. ONE whole-frame k-means
+           (T = 400 frames, K = 5, D = 576*3584)                                                            [HBM]
+  retrieve caption / dialogue embeddings -> cosine / flat-L2 top-k -> tree search                           [latency]
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from streamchat_amd import ops, streaming as S, synthetic, utiles as U, vision as V   # noqa: E402
+
+FRAMES = 1024
+MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)   # inference_streamchat_v0.3.sh:12-19
+GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
+MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+class Pipeline:
+    def __init__(self, device, n_frames, seed):
+        cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
+        self.cfg = cfg
+        self.sd_vit = V.random_clip_state_dict(cfg, seed=0, device=device)
+        self.sd_proj = V.random_projector_state_dict(1024, 3584, seed=1, device=device)
+        self.enc = V.FrameEncoder(V.CLIPVisionTower(self.sd_vit, cfg, device=device), V.MMProjector(self.sd_proj, device=device), micro_batch=64)
+        self.frames = torch.from_numpy(synthetic.frame_stream(n_frames, seed=seed)).to(device)        # resident in HBM
+        self.feats = torch.empty((n_frames, cfg.num_patches, 3584), dtype=torch.float16, device=device)
+        self.device = device
+        self.n = n_frames
+        # retrieval tables (synthetic): caption embeddings of the ceil(n/40) depth-0 nodes + 32 dialogue docs + queries
+        g = torch.Generator(device=device).manual_seed(7)
+        self.n_nodes = (n_frames + MEM["chunk_size"] - 1) // MEM["chunk_size"]
+        self.cap_emb = torch.randn(self.n_nodes + 8, 1024, device=device, generator=g)
+        self.q_emb = torch.randn(1024, device=device, generator=g)
+        self.doc_emb = torch.nn.functional.normalize(torch.randn(32, 384, device=device, generator=g), dim=1)
+        self.dq_emb = torch.nn.functional.normalize(torch.randn(384, device=device, generator=g), dim=0)
+        self.init_idx = None
+
+    def step(self):
+        # ---- encode ----
+        self.enc.encode_frames_u8(self.frames, out=self.feats)
+        bank = [self.feats[i:i + 1] for i in range(self.n)]
+        # ---- select (memory update; captions come from the synthetic captioner, untimed-equivalent host work) ----
+        cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
+        torch.manual_seed(0)                                  # init_idx = CPU randperm(T)[:K]  
+        tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
+        # ---- retrieve: dialogue memory (flat L2, k=1) + caption tree search (cosine, strict > 0 rule) ----
+        didx, _ = ops.sim_topk(self.dq_emb, self.doc_emb, 1, "l2")
+        picks = []
+        for node in tree:
+            if node.depth > 0:
+                idx, sc = ops.sim_topk(self.q_emb, self.cap_emb[: len(node.children)], 1, "cos")
+                picks.append(idx)
+        red = [n for n in tree if n.depth == 0]
+        if red:
+            idx, sc = ops.sim_topk(self.q_emb, self.cap_emb[: len(red)], 1, "cos")
+            picks.append(idx)
+        self.last = dict(tree=tree, short=short, doc=didx, picks=picks)
+        return self.last
+
+
+def cpu_baseline(pipe, n_cpu_frames):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+    import oracle
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.float().cpu() for k, v in pipe.sd_vit.items()}
+    sp = {k: v.float().cpu() for k, v in pipe.sd_proj.items()}
+    u8 = pipe.frames[:n_cpu_frames].cpu().numpy()
+    x = (u8.astype(np.float64) * (1 / 255)).astype(np.float32)
+    x = ((x - np.asarray(ops.CLIP_MEAN, np.float32)) / np.asarray(ops.CLIP_STD, np.float32)).transpose(0, 3, 1, 2)
+    t0 = time.time()
+    with torch.no_grad():
+        R.encode_images(sd, sp, torch.from_numpy(np.ascontiguousarray(x)), heads=16, patch=14, num_layers=24)
+    t_frame = (time.time() - t0) / n_cpu_frames
+    Tsub = 40
+    Xs = pipe.feats[:400:10].reshape(Tsub, -1).cpu().numpy()           # 40 of the 400 merge-group frames, full width
+    t0 = time.time()
+    r = oracle.kmeans_fit(Xs, 5, np.arange(0, Tsub, Tsub // 5, dtype=np.int32)[:5], np.zeros(50, np.int32), max_iter=2)
+    t_km_iter = (time.time() - t0) / (r["iters"] + 1) * (400 / Tsub)   # cost is linear in T
+    km_iters = 3
+    total = pipe.n * t_frame + km_iters * t_km_iter
+    return dict(value=round(pipe.n / total, 4), unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle/torch_ref ViT-L+projector fp32 on {n_cpu_frames} frames ({t_frame:.2f} s/frame) x{pipe.n}; "
+                       f"oracle k-means T={Tsub} of 400,K=5,D=2064384 scaled x10 ({t_km_iter:.2f} s/iter x {km_iters} iters); "
+                       "retrieval negligible")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    elif a.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    pipe = Pipeline(dev, a.frames, seed=1234 + rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        pipe.step()
+    barrier()
+    t0 = time.perf_counter()
+    with ops.KernelTimer() as kt:
+        for _ in range(a.steps):
+            pipe.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = kt.summary()
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    ms_step = dt / a.steps * 1e3
+    value = a.frames * world * a.steps / dt
+    n, ms, work = prof.get("k_gemm128", (0, 0.0, 0.0))
+    roof = dict(bound="mfma", kernel="k_gemm128", launches=n, avg_ms=round(ms / max(n, 1), 5),
+                achieved=round(work / max(ms, 1e-9) / 1e9, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
+                frac=round(work / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4), traffic=None)
+    stages = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in prof.items()}
+    if "kmeans_fit" in prof:
+        kn, kms, kw = prof["kmeans_fit"]
+        stages["kmeans_fit"]["note"] = "whole Lloyd fit (assign+update per iteration)"
+    out = dict(metric="frames/sec end-to-end (encode+select+retrieve), 1024-frame stream", value=round(value, 2), unit="frames/s",
+               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f16", data="synthetic",
+               config=dict(workload="C2: 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, "
+                                    "memory update (chunk 40, K 5, interval 10: one k-means T=400) + top-k retrieval; 7B prefill not yet in the timed region",
+                           frames_per_gpu=a.frames, micro_batch=64, parallelism=f"dp{world}", weights="random-init"),
+               roofline=roof, stages=stages)
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,47 @@ def _code(t: torch.Tensor) -> int:
 _ws_cache = {}
 
 
+class KernelTimer:
+    """Optional live timing of kernel launches with HIP events on the launch stream (bench.py's `roofline`
+    leg): `with ops.KernelTimer() as kt: ...; kt.summary()` -> {name: (launches, total_ms, total_work)}."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, work, e0, e1 in self.records:
+            n, ms, w = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), w + work)
+        return out
+
+
+class _timed:
+    def __init__(self, name, work):
+        self.kt = KernelTimer.active
+        if self.kt is not None:
+            self.name, self.work = name, work
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.kt is not None:
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.kt is not None:
+            self.e1.record()
+            self.kt.records.append((self.name, self.work, self.e0, self.e1))
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only per-device scratch (caller-owned memory handed to the library; 256-byte aligned)."""
     key = (torch.device(device).index or 0)
@@ -73,7 +114,7 @@ def kmeans_fit(X: torch.Tensor, K: int, init_idx, reseed_idx=None, weights=None,
     info = torch.zeros(4, dtype=torch.int32, device=dev)
     need = lib.sc_kmeans_workspace_bytes(T, D, K)
     ws = _workspace(need, dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("kmeans_fit", float(T) * D * X.element_size() + 2.0 * K * D * 4):
         check(lib.sc_kmeans_fit(ptr(X), _code(X), T, c_int64(D), K, ptr(w), ptr(init), ptr(rs), 0 if rs is None else rs.numel(),
                                 max_iter, c_float(tol), ptr(C), ptr(labels), ptr(wsum), ptr(info), ptr(ws), c_size_t(ws.numel()),
                                 stream_ptr(dev)), "sc_kmeans_fit")
@@ -176,7 +217,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
         raise StreamChatHipError("gemm: out/residual must be row-major")
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
-    with torch.cuda.device(a.device):
+    with torch.cuda.device(a.device), _timed("k_gemm128", 2.0 * M * N * K):
         check(lib.sc_gemm_f16(P(a), a.stride(0), P(w), P(bias), P(residual), 0 if residual is None else residual.stride(0), P(out),
                               out.stride(0), M, N, K, EPI[epilogue], 1 if out.dtype == torch.float32 else 0,
                               *((0, 0, 0) if a_rows is None else a_rows), stream_ptr(a.device)),
@@ -225,7 +266,7 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
     kl = None if kv_len is None else kv_len.to(device=q.device, dtype=torch.int32).contiguous()
-    with torch.cuda.device(q.device):
+    with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), out.stride(1), B, Sq, Skv, Hq, Hkv, Dh,
                                    c_float(scale), 1 if causal else 0, P(kl), stream_ptr(q.device)), "sc_attention_f16")
     return out

@@ -1,0 +1,99 @@
+"""Host-side mirror of the streaming entry point's hot functions
+(`/root/reference/inference_streaming_longva_v2.py`): frame sampling + encode (:454-531), memory update
+(:267-378) and answer-time retrieval/prompt assembly (:164-264).  Names and argument order follow the
+reference; tensors live in HBM and all arithmetic runs in the HIP kernels behind streamchat_amd.ops."""
+import numpy as np
+import torch
+
+from . import utiles as U
+from .conversation import conv_templates
+
+IMAGE_TOKEN_INDEX = -200            # longva/constants.py:8
+DEFAULT_IMAGE_TOKEN = "<image>"
+DEFAULT_IM_START_TOKEN = "<im_start>"
+DEFAULT_IM_END_TOKEN = "<im_end>"
+
+
+def sample_frame_indices(total_frames, frame_rate, start, end, sample_rate, chunk_size=30, clamp=(900, 200)):
+    """Integer frame-index arithmetic of video_reader_thread_with_embedding (:470-495).
+    `clamp=(900, 200)` reproduces the reference's `num_frame > 900 -> 200` guard (:484-485), which exists only
+    because it encodes a whole segment as ONE batch with 25 retained hidden states;
+    pass clamp=None to process every sampled frame (the encoder here is micro-batched)."""
+    start_frame = max(0, int(start * frame_rate))
+    end_frame = min(total_frames, int(end * frame_rate))
+    total_frames_to_process = end_frame - start_frame
+    num_frame = int(total_frames_to_process * sample_rate)
+    if clamp is not None and num_frame > clamp[0]:
+        num_frame = clamp[1]
+    if total_frames_to_process <= chunk_size:
+        return list(range(start_frame, end_frame))
+    return [int(start_frame + i * total_frames_to_process / num_frame) for i in range(num_frame)]
+
+
+def video_reader_thread_with_embedding(cap, total_frames, frame_rate, image_processor, model, start, end, device, sample_rate,
+                                       chunk_size=30, clamp=(900, 200)):
+    """Mirror of :454-531.  `cap` is anything with `read_rgb(frame_number) -> uint8 [H, W, 3]` (a cv2.VideoCapture
+    adapter or a synthetic stream); frames are decoded on the host, shipped as uint8 and preprocessed + encoded on
+    the GPU (`model.encode_frames_u8`), replacing the per-frame PIL -> numpy -> torch -> H2D float round trip of
+    :503-516.  Returns the feature bank: a list of [1, 576, D] views into ONE contiguous tensor."""
+    frame_indices = sample_frame_indices(total_frames, frame_rate, start, end, sample_rate, chunk_size, clamp)
+    frames = []
+    for current_frame_number in frame_indices:
+        fr = cap.read_rgb(current_frame_number)
+        if fr is None:
+            break
+        frames.append(fr)
+    if not frames:
+        return []
+    batch = frames[0].new_empty((len(frames),) + tuple(frames[0].shape)) if isinstance(frames[0], torch.Tensor) else None
+    if batch is None:
+        batch = torch.from_numpy(np.stack(frames))
+    else:
+        torch.stack(frames, out=batch)
+    with torch.no_grad():
+        image_embedding = model.encode_frames_u8(batch.to(device, non_blocking=True))
+    bs = image_embedding.shape[0]
+    feature_bank = [image_embedding[i:i + 1] for i in range(bs)]
+    assert len(feature_bank) == bs
+    return feature_bank
+
+
+def _captioning_ids(summarizer_model, summarizer_tokenzier):
+    captioning = ("Please describe what you see in this video in as much detail as possible from a first-person perspective, "
+                  "including the surrounding environment, what objects are there, etc.")
+    if getattr(summarizer_model.config, "mm_use_im_start_end", False):
+        qs = DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN + "\n" + captioning
+    else:
+        qs = DEFAULT_IMAGE_TOKEN + "\n" + captioning
+    conv = conv_templates["qwen_1_5_ego"].copy()
+    conv.append_message(conv.roles[0], qs)
+    conv.append_message(conv.roles[1], None)
+    from .mm_utils import tokenizer_image_token
+    ids = tokenizer_image_token(conv.get_prompt(), summarizer_tokenzier, IMAGE_TOKEN_INDEX, return_tensors="pt")
+    return ids.unsqueeze(0)
+
+
+def updating_memory_buffer(buffer_cache, long_memory_tree, summarizer_model, summarizer_tokenzier, building_multi_modal_memory_tree,
+                           short_window=20, remember_window=5, tau=5, compress_rate=1, chunk_size=30, num_clusters=5, interval=10,
+                           rng=None):
+    """Mirror of :267-378: short-term memory by forgetting-curve sampling over the last `short_window` frames,
+    long-term memory by chunking the whole buffer and growing the caption tree (at most one k-means merge)."""
+    captioning_input_ids = _captioning_ids(summarizer_model, summarizer_tokenzier)
+    if len(buffer_cache) > short_window:
+        waite_FIFO = buffer_cache[-short_window:]
+    else:
+        short_window = len(buffer_cache)
+        waite_FIFO = buffer_cache
+    remember_window_set = min(remember_window, len(waite_FIFO))
+    forgetting_probs = U.calculate_forgetting_probabilities(short_window, tau=tau)
+    short_memory_buffer = U.select_data_without_replacement(waite_FIFO, forgetting_probs, remember_window_set, rng=rng)
+
+    chunk_feature_list = [buffer_cache[i:i + chunk_size] for i in range(0, len(buffer_cache), chunk_size)]
+    # :347 — `len(chunk) > chunk_size` can never hold, so depth-0 nodes keep their raw frames (Q1)
+    k_means_chunk_feature_list = [U.weighted_kmeans_feature(U.cat_frames(c), num_clusters)[0] if len(c) > chunk_size else U.cat_frames(c)
+                                  for c in chunk_feature_list]
+    long_memory_tree = U.fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_clusters, interval, summarizer_model,
+                                                                   captioning_input_ids, summarizer_tokenzier, chunk_feature_list,
+                                                                   long_memory_tree)
+    assert len(short_memory_buffer) > 0, "No memory ?"
+    return long_memory_tree, short_memory_buffer

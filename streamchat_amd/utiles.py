@@ -48,6 +48,24 @@ class MultimodalTreeNode:
         self.depth = depth
 
 
+def cat_frames(tensors):
+    """torch.cat(list, dim=0) — but adjacent views of one contiguous feature bank are returned as a VIEW
+    (the reference's cat copies up to 1.65 GB per merge; the feature bank here is one tensor)."""
+    t0 = tensors[0]
+    if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] for t in tensors):
+        row = t0[0].numel() * t0.element_size()
+        ptr, ok = t0.data_ptr(), True
+        for t in tensors:
+            if t.data_ptr() != ptr or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr():
+                ok = False
+                break
+            ptr += t.shape[0] * row
+        if ok:
+            n = sum(t.shape[0] for t in tensors)
+            return torch.as_strided(t0, (n,) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(tensors, dim=0)
+
+
 # ------------------------------------------------------------------------------------------------
 # short-term memory: forgetting-curve sampling (host; reference utiles.py:251-262)
 # ------------------------------------------------------------------------------------------------
@@ -163,7 +181,7 @@ def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_cl
     output_list = []
     for chunk_feature in chunked_feature_list:
         dimension = chunk_feature[0].shape[-1]
-        chunk_feature = torch.cat(chunk_feature, dim=0).reshape(-1, dimension).to(summarizer.device)
+        chunk_feature = cat_frames(chunk_feature).reshape(-1, dimension).to(summarizer.device)
         with torch.no_grad():
             output_ids = summarizer.generate_with_image_embedding(
                 input_ids.to(summarizer.device), image_embeddings=[chunk_feature], modalities=["video"],
@@ -184,7 +202,7 @@ def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_cl
         chunk = nodes[start_index: start_index + interval]
         centroids_list = [node.centroids for node in chunk]
         caption_list = [node.text for node in chunk]
-        combined_centroids = torch.cat(centroids_list, dim=0)
+        combined_centroids = cat_frames(centroids_list)
         if combined_centroids.shape[0] > num_clusters:
             new_centroids, labels = weighted_kmeans_feature(combined_centroids, num_clusters)
         else:
