@@ -137,7 +137,7 @@ int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float eps, void* y
  *   k,v [B, Skv, Hkv, Dh]  row strides ldk / ldv (GQA: Hq % Hkv == 0)
  *   out [B, Sq,  Hq,  Dh]  row stride ldo
  *   causal: 0 = full; 1 = causal with the Sq queries aligned to the END of the Skv keys
- *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {64, 128}. */
+ *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {32, 64, 128}. */
 int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                      int ldo, int B, int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal,
                      const int32_t* kv_len, sc_stream_t stream);

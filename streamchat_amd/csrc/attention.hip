@@ -70,7 +70,12 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
         const int q = j * 256 + tid;
-        if (DH == 64) {
+        if (DH == 32) {                         // 64-byte rows: 4 granules
+            k_r[j] = q >> 2;
+            k_s[j] = (q & 3) ^ ((0x78 >> (2 * ((k_r[j] >> 2) & 3))) & 3);      // f = {0,2,3,1}[(row>>2)&3]
+            v_r[j] = q >> 2;
+            v_s[j] = (q & 3) ^ (((v_r[j] >> 2) & 1) << 1);
+        } else if (DH == 64) {
             k_r[j] = 2 * (q >> 4) + ((q & 15) >> 3);
             k_s[j] = (q & 7) ^ ((q >> 4) & 7);
             v_r[j] = q >> 3;
@@ -100,7 +105,8 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
     int k_off[DS];   // K fragment byte offset of (row rl, d-step ds) inside a 16-row block
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) {
-        if (DH == 64) k_off[ds] = (rl >> 1) * 256 + ((((rl & 1) << 3) | ((ds * 4 + g) ^ ((rl >> 1) & 7))) << 4);
+        if (DH == 32) k_off[ds] = rl * 64 + ((g ^ ((0x78 >> (2 * ((rl >> 2) & 3))) & 3)) << 4);
+        else if (DH == 64) k_off[ds] = (rl >> 1) * 256 + ((((rl & 1) << 3) | ((ds * 4 + g) ^ ((rl >> 1) & 7))) << 4);
         else k_off[ds] = rl * 256 + (((ds * 4 + g) ^ rl) << 4);
     }
     constexpr int KBLK = 16 * DH * 2;             // bytes per 16 kv rows
@@ -110,7 +116,8 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
     int v_off[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-        if (DH == 64) v_off[db] = vrow * 128 + ((db ^ ((vrow >> 1) & 3)) << 5) + (rl & 3) * 8;
+        if (DH == 32) v_off[db] = vrow * 64 + ((db ^ (g & 1)) << 5) + (rl & 3) * 8;
+        else if (DH == 64) v_off[db] = vrow * 128 + ((db ^ ((vrow >> 1) & 3)) << 5) + (rl & 3) * 8;
         else v_off[db] = vrow * 256 + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
     }
     constexpr int VROW = DH * 2;
@@ -256,5 +263,5 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     hipStream_t s = (hipStream_t)stream;
     if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
     if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
-    return sc_fail(SC_ERR_UNSUPPORTED, "sc_attention_f16: head dim 32 not built yet");
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
 }
