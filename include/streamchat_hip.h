@@ -131,6 +131,16 @@ int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta
 int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float eps, void* y, int ldy, int rows,
                    int cols, sc_stream_t stream);
 
+/* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
+ * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
+ *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)
+ *   sc_pool_f16: mode 0 = CLS row, mode 1 = mean over the first len[b] tokens (len NULL = L); optional L2
+ *                normalisation; out [B, H] fp32. */
+int sc_bert_embed_ln_f16(const int32_t* ids, const void* word, const void* pos, const void* type0,
+                         const void* gamma, const void* beta, float eps, void* out, int B, int L, int H,
+                         int vocab, sc_stream_t stream);
+int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L, int H, int mode,
+                int normalize, sc_stream_t stream);
 /* Fused softmax(Q K^T * scale [+ mask]) V, fp16 in/out, fp32 online softmax (flash-style, S x S never
  * materialised).  Token-major layouts with explicit row strides (so q/k/v may alias one fused QKV buffer):
  *   q   [B, Sq,  Hq,  Dh]  row stride ldq elements, head h at column h*Dh

@@ -66,3 +66,37 @@ def encode_images(sd_vit, sd_proj, pixel_values, *, heads, patch, num_layers, se
     run = num_layers + 1 + select_layer if select_layer < 0 else select_layer
     h = clip_vision_hidden(sd_vit, pixel_values, heads=heads, patch=patch, layers_run=run)
     return mm_projector(sd_proj, h[:, 1:])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BERT (HF BertModel; call sites reference utiles.py:707,728 and local_doc_qa.py:193 via sentence-transformers)
+# ---------------------------------------------------------------------------------------------------------
+def bert_last_hidden(sd, input_ids, attention_mask, *, heads, layers, eps=1e-12, prefix=""):
+    p = prefix
+    B, L = input_ids.shape
+    x = sd[p + "embeddings.word_embeddings.weight"][input_ids] + sd[p + "embeddings.token_type_embeddings.weight"][0] \
+        + sd[p + "embeddings.position_embeddings.weight"][:L][None]
+    x = _ln(x, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], eps)
+    D = x.shape[-1]
+    dh = D // heads
+    neg = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+    for i in range(layers):
+        lp = f"{p}encoder.layer.{i}."
+        lin = lambda n, t: F.linear(t, sd[lp + n + ".weight"], sd[lp + n + ".bias"])
+        q = lin("attention.self.query", x).view(B, L, heads, dh).transpose(1, 2)
+        k = lin("attention.self.key", x).view(B, L, heads, dh).transpose(1, 2)
+        v = lin("attention.self.value", x).view(B, L, heads, dh).transpose(1, 2)
+        a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + neg, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, L, D)
+        x = _ln(lin("attention.output.dense", a) + x, sd[lp + "attention.output.LayerNorm.weight"], sd[lp + "attention.output.LayerNorm.bias"], eps)
+        f = F.gelu(lin("intermediate.dense", x))
+        x = _ln(lin("output.dense", f) + x, sd[lp + "output.LayerNorm.weight"], sd[lp + "output.LayerNorm.bias"], eps)
+    return x
+
+
+def sentence_embedding(sd, input_ids, attention_mask, *, heads, layers):
+    """sentence-transformers all-MiniLM-L6-v2: mean pooling over the attention mask, then L2 normalise."""
+    h = bert_last_hidden(sd, input_ids, attention_mask, heads=heads, layers=layers)
+    m = attention_mask[..., None].to(h.dtype)
+    e = (h * m).sum(1) / m.sum(1).clamp(min=1e-9)
+    return F.normalize(e, p=2, dim=1)

@@ -128,6 +128,87 @@ __global__ __launch_bounds__(256) void k_vit_embed_ln(const _Float16* __restrict
     }
 }
 
+// BERT embeddings: word[ids] + position[pos] + token_type[0] -> LayerNorm (HF BertEmbeddings); one wave per token
+template <int NV>
+__global__ __launch_bounds__(256) void k_bert_embed_ln(const int* __restrict__ ids, const _Float16* __restrict__ word,
+                                                       const _Float16* __restrict__ pos, const _Float16* __restrict__ type0,
+                                                       const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps,
+                                                       _Float16* __restrict__ out, int rows, int L, int H, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const _Float16* wr = word + (size_t)id * H;
+    const _Float16* pr = pos + (size_t)(row % L) * H;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < H) {
+            const sc_h8 a = *reinterpret_cast<const sc_h8*>(wr + c);
+            const sc_h8 b = *reinterpret_cast<const sc_h8*>(pr + c);
+            const sc_h8 t = *reinterpret_cast<const sc_h8*>(type0 + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e] + (float)t[e] + (float)b[e]; s += v[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < H) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)H + eps);
+    _Float16* yr = out + (size_t)row * (size_t)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < H) {
+            const sc_h8 g = *reinterpret_cast<const sc_h8*>(gamma + c);
+            const sc_h8 b = *reinterpret_cast<const sc_h8*>(beta + c);
+            sc_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((v[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            *reinterpret_cast<sc_h8*>(yr + c) = o;
+        }
+    }
+}
+
+// sentence pooling: mode 0 = CLS row, 1 = masked mean over the first len[b] tokens; optional L2 normalisation; fp32 out
+__global__ __launch_bounds__(256) void k_pool(const _Float16* __restrict__ h, const int* __restrict__ len, float* __restrict__ out, int L, int H,
+                                              int mode, int normalize) {
+    const int b = blockIdx.x;
+    __shared__ float red[4];
+    const _Float16* hb = h + (size_t)b * L * H;
+    const int n = mode == 0 ? 1 : (len ? (len[b] < L ? len[b] : L) : L);
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float a = 0.f;
+        for (int t = 0; t < n; ++t) a += (float)hb[(size_t)t * H + c];
+        a = mode == 0 ? a : a / fmaxf((float)n, 1e-9f);
+        out[(size_t)b * H + c] = a;
+        ss += a * a;
+    }
+    if (!normalize) return;
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) out[(size_t)b * H + c] *= inv;
+}
+
 template <bool RMS>
 int launch_norm(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y, int ldy, int rows, int cols,
                 hipStream_t s, const char* name) {
@@ -183,5 +264,30 @@ extern "C" int sc_vit_embed_ln_f16(const void* patch, const void* cls, const voi
     if (nv <= 1) SC_EMB(1); else if (nv <= 2) SC_EMB(2); else if (nv <= 4) SC_EMB(4); else SC_EMB(8);
 #undef SC_EMB
     SC_CHECK_LAUNCH("sc_vit_embed_ln_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_bert_embed_ln_f16(const int32_t* ids, const void* word, const void* pos, const void* type0, const void* gamma,
+                                    const void* beta, float eps, void* out, int B, int L, int H, int vocab, sc_stream_t stream) {
+    SC_REQUIRE(ids && word && pos && type0 && gamma && beta && out, "sc_bert_embed_ln_f16: null pointer argument");
+    SC_REQUIRE(B > 0 && L > 0 && H > 0 && H % 8 == 0 && H <= 4096 && vocab > 0, "sc_bert_embed_ln_f16: bad sizes");
+    const int rows = B * L;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nv = (H + 511) / 512;
+    hipStream_t s = (hipStream_t)stream;
+#define SC_EMB(NV) hipLaunchKernelGGL((k_bert_embed_ln<NV>), grid, block, 0, s, ids, (const _Float16*)word, (const _Float16*)pos, (const _Float16*)type0, \
+                                      (const _Float16*)gamma, (const _Float16*)beta, eps, (_Float16*)out, rows, L, H, vocab)
+    if (nv <= 1) SC_EMB(1); else if (nv <= 2) SC_EMB(2); else if (nv <= 4) SC_EMB(4); else SC_EMB(8);
+#undef SC_EMB
+    SC_CHECK_LAUNCH("sc_bert_embed_ln_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L, int H, int mode, int normalize,
+                           sc_stream_t stream) {
+    SC_REQUIRE(hidden && out, "sc_pool_f16: null pointer argument");
+    SC_REQUIRE(B > 0 && L > 0 && H > 0 && (mode == 0 || mode == 1), "sc_pool_f16: bad sizes / mode");
+    hipLaunchKernelGGL(k_pool, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)hidden, len, out, L, H, mode, normalize);
+    SC_CHECK_LAUNCH("sc_pool_f16");
     return SC_OK;
 }

@@ -299,3 +299,32 @@ def patchify_f16(pixel_values: torch.Tensor, patch: int, ld: int, out=None) -> t
     with torch.cuda.device(x.device):
         check(lib.sc_patchify_f16(ptr(x), n, h, w, patch, ptr(out), ld, stream_ptr(x.device)), "sc_patchify_f16")
     return out
+
+
+def bert_embed_ln(ids, word, pos, type0, gamma, beta, eps: float, out=None):
+    """ids int32 [B, L] -> fp16 [B*L, H] = LN(word[ids] + pos[t] + type0)."""
+    _require_cuda(ids, word)
+    lib = _lib.load()
+    B, L = ids.shape
+    H = word.shape[1]
+    ids = ids.to(torch.int32).contiguous()
+    if out is None:
+        out = torch.empty((B * L, H), dtype=torch.float16, device=word.device)
+    with torch.cuda.device(word.device):
+        check(lib.sc_bert_embed_ln_f16(ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(beta), c_float(eps), ptr(out), B, L, H,
+                                       word.shape[0], stream_ptr(word.device)), "sc_bert_embed_ln_f16")
+    return out
+
+
+def pool(hidden, lengths=None, mode: str = "cls", normalize: bool = False):
+    """hidden fp16 [B, L, H] -> fp32 [B, H]: CLS row or masked mean (+ optional L2 normalisation)."""
+    _require_cuda(hidden)
+    lib = _lib.load()
+    B, L, H = hidden.shape
+    hidden = hidden.contiguous()
+    ln = None if lengths is None else lengths.to(device=hidden.device, dtype=torch.int32).contiguous()
+    out = torch.empty((B, H), dtype=torch.float32, device=hidden.device)
+    with torch.cuda.device(hidden.device):
+        check(lib.sc_pool_f16(ptr(hidden), ptr(ln), ptr(out), B, L, H, 0 if mode == "cls" else 1, 1 if normalize else 0,
+                              stream_ptr(hidden.device)), "sc_pool_f16")
+    return out

@@ -1,0 +1,48 @@
+"""CPU: oracle/torch_ref.py (fp32 restatement of the transformers arithmetic) against golden vectors produced by the
+REAL HF modules (tools/make_golden_hf.py) — this is what pins the third-party part of the oracle."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import torch_ref as R
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_clip_tower_and_projector_vs_hf():
+    d = np.load(os.path.join(G, "clip_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("vit.")}
+    sp = {k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("proj.")}
+    px = torch.from_numpy(d["pixel_values"])
+    h = R.clip_vision_hidden(sd, px, heads=2, patch=14, layers_run=2)           # hidden_states[-2] of a 3-layer tower
+    torch.testing.assert_close(h[:, 1:], torch.from_numpy(d["features"]), rtol=1e-4, atol=1e-5)
+    y = R.encode_images(sd, sp, px, heads=2, patch=14, num_layers=3)
+    torch.testing.assert_close(y, torch.from_numpy(d["projected"]), rtol=1e-4, atol=1e-5)
+
+
+def test_bert_vs_hf():
+    d = np.load(os.path.join(G, "bert_tiny.npz"))
+    sd = {k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("bert.")}
+    ids, mask = torch.from_numpy(d["input_ids"]), torch.from_numpy(d["attention_mask"])
+    h = R.bert_last_hidden(sd, ids, mask, heads=4, layers=2)
+    m = mask.bool()
+    torch.testing.assert_close(h[m], torch.from_numpy(d["last_hidden_state"])[m], rtol=1e-4, atol=1e-5)
+    e = R.sentence_embedding(sd, ids, mask, heads=4, layers=2)
+    torch.testing.assert_close(e.norm(dim=1), torch.ones(3), rtol=1e-5, atol=1e-5)
+
+
+def test_tokenizer_image_token_vs_reference():
+    from streamchat_amd.mm_utils import tokenizer_image_token
+    import types
+
+    class Tok:
+        def __init__(s, bos):
+            s.bos_token_id = bos
+
+        def __call__(s, t):
+            ids = [ord(c) % 50 + 2 for c in t]
+            return types.SimpleNamespace(input_ids=([s.bos_token_id] + ids) if s.bos_token_id is not None else ids)
+    for c in json.load(open(os.path.join(G, "tokenizer_image_token.json"))):
+        assert tokenizer_image_token(c["prompt"], Tok(c["bos"]), -200) == c["ids"]

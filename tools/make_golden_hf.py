@@ -42,9 +42,35 @@ def gen_clip():
     np.savez_compressed(os.path.join(OUT, "clip_tiny.npz"), **d)
 
 
+def gen_bert():
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(1)
+    cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                     max_position_embeddings=64, hidden_act="gelu", layer_norm_eps=1e-12)
+    m = BertModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn_like(p) * (0.3 if "embeddings" in n else 0.6 / p.shape[-1] ** 0.5))
+            else:
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if n.endswith("LayerNorm.weight") else 0.0))
+    ids = torch.randint(5, 500, (3, 11))
+    mask = torch.ones(3, 11, dtype=torch.long)
+    mask[1, 7:] = 0
+    mask[2, 3:] = 0
+    ids = ids * mask
+    with torch.no_grad():
+        h = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    d = {"input_ids": ids.numpy(), "attention_mask": mask.numpy(), "last_hidden_state": h.numpy(), "cfg_heads": 4, "cfg_layers": 2}
+    for k, v in m.state_dict().items():
+        d["bert." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "bert_tiny.npz"), **d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("authoring container only")
     torch.set_num_threads(1)
     gen_clip()
-    print("transformers", transformers.__version__, "-> clip_tiny.npz")
+    gen_bert()
+    print("transformers", transformers.__version__, "-> clip_tiny.npz bert_tiny.npz")
