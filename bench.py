@@ -21,7 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from streamchat_amd import ops, streaming as S, synthetic, utiles as U, vision as V   # noqa: E402
+from streamchat_amd import ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
+from streamchat_amd.memory_bank.memory_retrieval import local_doc_qa as Q   # noqa: E402
 
 FRAMES = 1024
 MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)   # inference_streamchat_v0.3.sh:12-19
@@ -52,14 +53,15 @@ class Pipeline:
         self.feats = torch.empty((n_frames, cfg.num_patches, 3584), dtype=torch.float16, device=device)
         self.device = device
         self.n = n_frames
-        # retrieval tables (synthetic): caption embeddings of the ceil(n/40) depth-0 nodes + 32 dialogue docs + queries
-        g = torch.Generator(device=device).manual_seed(7)
-        self.n_nodes = (n_frames + MEM["chunk_size"] - 1) // MEM["chunk_size"]
-        self.cap_emb = torch.randn(self.n_nodes + 8, 1024, device=device, generator=g)
-        self.q_emb = torch.randn(1024, device=device, generator=g)
-        self.doc_emb = torch.nn.functional.normalize(torch.randn(32, 384, device=device, generator=g), dim=1)
-        self.dq_emb = torch.nn.functional.normalize(torch.randn(384, device=device, generator=g), dim=0)
-        self.init_idx = None
+        # retrieval models: BERT-large (mxbai-colbert as the reference loads it: plain encoder, CLS) for the caption tree,
+        # all-MiniLM-L6 (mean-pool + L2-normalise) for the dialogue memory; random-init, hash tokenizer (offline)
+        bl, ml = T.BertConfigLite(**T.BERT_LARGE), T.BertConfigLite(**T.MINILM_L6)
+        self.colbert = T.BertEncoder(T.random_bert_state_dict(bl, seed=2, device=device), bl, device=device)
+        self.tok = T.HashTokenizer()
+        self.sent = Q.HipSentenceEmbeddings(T.SentenceEmbedder(T.BertEncoder(T.random_bert_state_dict(ml, seed=3, device=device), ml, device=device)), self.tok)
+        self.docs = [Q.Document(f"Conversation content on 2024-05-{1 + i // 8:02d}:[|User|]: {synthetic.caption(100 + i, words=8)}; "
+                                f"[|AI|]: {synthetic.caption(200 + i, words=10)}", {"source": f"2024-05-{1 + i // 8:02d}"}) for i in range(32)]
+        self.question = "where did I leave the red cup and what was on the kitchen table"
 
     def step(self):
         # ---- encode ----
@@ -69,18 +71,16 @@ class Pipeline:
         cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
         torch.manual_seed(0)                                  # init_idx = CPU randperm(T)[:K]  
         tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
-        # ---- retrieve: dialogue memory (flat L2, k=1) + caption tree search (cosine, strict > 0 rule) ----
-        didx, _ = ops.sim_topk(self.dq_emb, self.doc_emb, 1, "l2")
-        picks = []
-        for node in tree:
-            if node.depth > 0:
-                idx, sc = ops.sim_topk(self.q_emb, self.cap_emb[: len(node.children)], 1, "cos")
-                picks.append(idx)
-        red = [n for n in tree if n.depth == 0]
-        if red:
-            idx, sc = ops.sim_topk(self.q_emb, self.cap_emb[: len(red)], 1, "cos")
-            picks.append(idx)
-        self.last = dict(tree=tree, short=short, doc=didx, picks=picks)
+        # ---- retrieve: dialogue memory (MiniLM, flat L2, k=1, rebuilt per round like memory_utils.py:76-83) ----
+        lm = Q.LocalMemoryRetrieval()
+        lm.init_cfg("minilm-l6", top_k=1, language="en", embedder=self.sent)
+        store = Q.FlatL2VectorStore(self.docs, lm._embed_docs(self.docs), self.sent.embed_query)
+        related, dates = lm.search_memory(self.question, store)
+        # ---- retrieve: caption-tree search (BERT-large CLS + cosine, strict > 0 rule, utiles.py:685-788) ----
+        short_emb = U.cat_frames(short).view(-1, short[0].shape[-1])
+        path_feats, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, short_emb, self.colbert, self.tok,
+                                                                              cache=U.CaptionEmbeddingCache())
+        self.last = dict(tree=tree, short=short, related=related, path_text=path_text, path_feats=path_feats)
         return self.last
 
 

@@ -245,10 +245,21 @@ def _cls_embed(model, tokenizer, text, device):
 
 
 class CaptionEmbeddingCache:
-    """Caption -> embedding table.  The reference re-encodes every visited caption on every query
-    (utiles.py:721-732); captions never change once a node exists, so they are encoded once."""
+    """Caption -> embedding table.  The reference re-encodes every visited caption on every query, one text per
+    forward with a host sync each (utiles.py:696,721-732); captions never change once a node exists, so they are
+    encoded once, and all uncached captions of a sibling set go through the encoder as ONE padded batch."""
     def __init__(self):
         self.table = {}
+
+    def get_many(self, model, tokenizer, texts, device, batch=True):
+        todo = [t for t in dict.fromkeys(texts) if (id(model), t) not in self.table]
+        if todo and batch and len(todo) > 1:
+            ids = tokenizer(todo, padding=True, return_tensors="pt")
+            ids = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in ids.items()}
+            out = model(**ids).last_hidden_state[:, 0].detach().to(torch.float32)
+            for t, e in zip(todo, out):
+                self.table[(id(model), t)] = e
+        return [self.get(model, tokenizer, t, device) for t in texts]
 
     def get(self, model, tokenizer, text, device):
         key = (id(model), text)
@@ -271,7 +282,8 @@ def _best_positive(query_embedding, embeddings):
     return (i if s > 0 else None), s
 
 
-def fast_search_tree_multi_modal_with_embedding(all_nodes, query, image_embedding, model, tokenizer, top_k=1, cache=None):
+def fast_search_tree_multi_modal_with_embedding(all_nodes, query, image_embedding, model, tokenizer, top_k=1, cache=None,
+                                                batch_captions=True):
     """Drop-in for reference utiles.py:685-788: for every top-level node of depth > 0 walk down the
     best-cosine child at each level (appending the CHILD's features/text — Q8); among the depth-0
     top-level ("redundant") nodes append the best one.  Returns (path_features, path_text).
@@ -290,7 +302,7 @@ def fast_search_tree_multi_modal_with_embedding(all_nodes, query, image_embeddin
             redundant_nodes.append(node)
             continue
         while current_node.children:
-            embs = [cache.get(model, tokenizer, child.text, device) for child in current_node.children]
+            embs = cache.get_many(model, tokenizer, [child.text for child in current_node.children], device, batch_captions)
             best_child_index, _ = _best_positive(query_embedding, embs)
             if best_child_index is None:
                 best_child_index = 0
@@ -299,7 +311,7 @@ def fast_search_tree_multi_modal_with_embedding(all_nodes, query, image_embeddin
             current_node = current_node.children[best_child_index]
 
     if len(redundant_nodes) >= 1:
-        embs = [cache.get(model, tokenizer, n.text, device) for n in redundant_nodes]
+        embs = cache.get_many(model, tokenizer, [n.text for n in redundant_nodes], device, batch_captions)
         best_index, _ = _best_positive(query_embedding, embs)
         if best_index is None:
             best_index = 0

@@ -91,7 +91,7 @@ def test_tree_search_matches_reference_golden():
             c = N(torch.full((2, 2, 4), 102.0, device="cuda"), "C", depth=1); c.children = l[6:9]
             nodes = [root, c, leaf("red1", 50), leaf("red2", 51)]
         feats, txt = U.fast_search_tree_multi_modal_with_embedding(nodes, "QUERY", torch.zeros(1, device="cuda"), _Model(texts), _Tok(),
-                                                                   cache=U.CaptionEmbeddingCache())
+                                                                   cache=U.CaptionEmbeddingCache(), batch_captions=False)
         assert txt == case["path_text"]
         assert [float(f.flatten()[0]) for f in feats] == case["path_first_value"]
         assert [list(f.shape) for f in feats] == case["path_shapes"]

@@ -335,6 +335,91 @@ def gen_search(ns):
     json.dump(cases, open(os.path.join(OUT, "search.json"), "w"))
 
 
+# ------------------------------------------------------------------------------------------
+# G9b  dialogue memory: JsonMemoryLoader.load, the patched FAISS search with neighbour expansion
+# and search_memory (memory_bank/memory_retrieval/local_doc_qa.py:17-61,120-178,263-288), run on
+# stand-ins for the absent langchain / faiss objects (exact flat-L2 index, dict docstore).
+# ------------------------------------------------------------------------------------------
+class _Doc:
+    def __init__(self, page_content, metadata):
+        self.page_content, self.metadata = page_content, metadata
+
+
+class _Loader:     # stand-in for langchain's UnstructuredFileLoader base
+    def __init__(self, filepath, mode="elements"):
+        self.file_path = filepath
+
+
+def _text_vec(text, d=24):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(text.encode()))
+    v = rng.standard_normal(d).astype(np.float32)
+    return v / np.linalg.norm(v)
+
+
+class _FlatL2:
+    def __init__(self, X):
+        self.X = X
+
+    def search(self, q, k):
+        d = ((self.X - q[0][None]) ** 2).sum(1)
+        order = np.argsort(d, kind="stable")[:k]
+        idx = np.full((1, k), -1, np.int64); sc = np.full((1, k), np.inf, np.float32)
+        idx[0, : len(order)] = order; sc[0, : len(order)] = d[order]
+        return sc, idx
+
+
+class _Docstore:
+    def __init__(self, docs):
+        self.d = {str(i): doc for i, doc in enumerate(docs)}
+
+    def search(self, _id):
+        return self.d[_id]
+
+
+def gen_memory():
+    import tempfile
+    src = open(os.path.join(REF, "memory_bank/memory_retrieval/local_doc_qa.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    ns = dict(np=np, json=json, os=os, List=list, Tuple=tuple, Optional=None, Document=_Doc, UnstructuredFileLoader=_Loader,
+              VECTOR_SEARCH_TOP_K=3, CHUNK_SIZE=200, EMBEDDING_MODEL_CN="", EMBEDDING_DEVICE="cpu", TextSplitter=None)
+    import typing
+    ns.update(List=typing.List, Tuple=typing.Tuple, Optional=typing.Optional)
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef) and n.name in ("seperate_list", "similarity_search_with_score_by_vector", "get_docs_with_score"):
+            exec(compile(ast.Module([n], []), "local_doc_qa.py", "exec"), ns)
+        if isinstance(n, ast.ClassDef) and n.name in ("JsonMemoryLoader", "LocalMemoryRetrieval"):
+            exec(compile(ast.Module([n], []), "local_doc_qa.py", "exec"), ns)
+    memory = {"User": {"name": "User", "history": {
+        "2024-05-01": [{"query": "where did I leave the red cup", "response": "on the kitchen counter next to the sink"},
+                       {"query": "what colour is the car outside", "response": "a blue hatchback"},
+                       {"query": "who was at the door", "response": "a courier with a small parcel"}],
+        "2024-05-02": [{"query": "did I lock the bicycle", "response": "yes, to the rack near the stairs"},
+                       {"query": "what is on the laptop screen " + "very " * 30 + "long", "response": "a spreadsheet " + "with rows " * 12},
+                       {"query": "what did the sign say", "response": "road closed ahead"}]},
+        "summary": {"2024-05-01": "the user asked about a cup, a car and a courier"}},
+        "Other": {"name": "Other", "history": {"2024-05-01": [{"query": "x", "response": "y"}]}}}
+    tmp = tempfile.mkdtemp()
+    fp = os.path.join(tmp, "memory_0.json")
+    json.dump(memory, open(fp, "w"))
+    docs = ns["JsonMemoryLoader"](fp, "en").load("User")
+    loaded = [dict(page_content=d.page_content, source=d.metadata["source"]) for d in docs]
+    cases = []
+    for top_k in (1, 2, 3):
+        for query in ["where is my red cup", "bicycle lock", "what did the road sign say", "laptop screen spreadsheet", "courier parcel door"]:
+            fresh = ns["JsonMemoryLoader"](fp, "en").load("User")      # search mutates page_content
+            X = np.stack([_text_vec(d.page_content) for d in fresh])
+            vs = types.SimpleNamespace(index=_FlatL2(X), index_to_docstore_id={i: str(i) for i in range(len(fresh))},
+                                       docstore=_Docstore(fresh), chunk_size=200)
+            vs.similarity_search_with_score = lambda q, k, vs=vs: ns["similarity_search_with_score_by_vector"](vs, _text_vec(q).tolist(), k)
+            lm = ns["LocalMemoryRetrieval"]()
+            lm.top_k = top_k
+            date_docs, dates = lm.search_memory(query, vs)
+            cases.append(dict(query=query, top_k=top_k, date_docs=date_docs, dates=dates))
+    json.dump(dict(memory=memory, loaded=loaded, cases=cases, embed="crc32-seeded unit vectors d=24 (tools/make_golden.py:_text_vec)"),
+              open(os.path.join(OUT, "memory_search.json"), "w"))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: golden vectors can only be generated in the authoring container")
@@ -348,6 +433,7 @@ def main():
         gen_forgetting(ns)
         gen_tree(ns)
         gen_search(ns)
+        gen_memory()
     print(f"wrote {n} k-means cases + forgetting/tree/search fixtures to {os.path.normpath(OUT)}")
     meta = dict(torch=torch.__version__, numpy=np.__version__, reference="hmxiong/StreamChat @ 2025-03-14",
                 functions=sorted(WANT))
