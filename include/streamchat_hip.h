@@ -107,7 +107,9 @@ int sc_sim_topk(const float* q, const float* docs, int M, int d, int k, int metr
  * longva/model/multimodal_encoder/clip_encoder.py:76, multimodal_projector/builder.py:41-48,
  * utiles.py:707,728 and longva/model/language_model/llava_qwen.py:155.
  */
-enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2 };
+enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2, SC_EPI_SWIGLU = 3 };
+/* SC_EPI_SWIGLU: W rows are interleaved per 4 output columns as (gate_j, gate_j+1, up_j, up_j+1); the kernel writes
+ * silu(gate) * up to C[M, N/2] (Qwen2MLP act_fn(gate_proj(x)) * up_proj(x) without the [M, 2I] intermediate). */
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N]).  fp16 in, fp32 accumulate (MFMA),
  * fp16 out (out_f32 = 0) or fp32 out (out_f32 = 1).  W has the torch.nn.Linear layout [N, K].
  * lda / ldr / ldc in elements.  Requirements: K % 64 == 0, N % 128 == 0, A and W 16-byte aligned,
@@ -131,6 +133,13 @@ int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta
 int sc_rmsnorm_f16(const void* x, int ldx, const void* gamma, float eps, void* y, int ldy, int rows,
                    int cols, sc_stream_t stream);
 
+/* Qwen2 helpers.  sc_gather_rows_f16: out[r] = table[ids[r]] (embed_tokens; ids < 0 -> zero row, filled by the image
+ * splice of llava_arch.py:208-343).  sc_rope_f16: rotate-half rotary embedding in place on `heads` heads of width Dh at
+ * column 0 of every row (positions NULL -> pos0 + row), HF apply_rotary_pos_emb numerics. */
+int sc_gather_rows_f16(const int32_t* ids, const void* table, void* out, int rows, int H, int ldo, int vocab,
+                       sc_stream_t stream);
+int sc_rope_f16(void* x, int ld, const int32_t* positions, int pos0, int rows, int heads, int Dh, float theta,
+                sc_stream_t stream);
 /* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
  * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
  *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)

@@ -100,3 +100,43 @@ def sentence_embedding(sd, input_ids, attention_mask, *, heads, layers):
     m = attention_mask[..., None].to(h.dtype)
     e = (h * m).sum(1) / m.sum(1).clamp(min=1e-9)
     return F.normalize(e, p=2, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Qwen2 (HF Qwen2ForCausalLM; call site reference llava_qwen.py:155)
+# ---------------------------------------------------------------------------------------------------------
+def _rms(x, w, eps):
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return w * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
+
+
+def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6):
+    """logits [L, vocab] for inputs_embeds [L, H] (causal, positions 0..L-1): RMSNorm -> q/k/v (bias) -> rotate-half RoPE ->
+    GQA causal attention -> o_proj -> +res -> RMSNorm -> down(silu(gate) * up) -> +res; final norm; lm_head."""
+    L, H = embeds.shape
+    x = embeds
+    pos = torch.arange(L, device=x.device, dtype=torch.float32)
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, device=x.device, dtype=torch.float32) / head_dim))
+    fr = torch.outer(pos, inv)
+    cos, sin = torch.cat([fr, fr], -1).cos(), torch.cat([fr, fr], -1).sin()
+
+    def rot(t):                                   # t [h, L, d]
+        t1, t2 = t[..., : head_dim // 2], t[..., head_dim // 2:]
+        return t * cos + torch.cat([-t2, t1], -1) * sin
+    mask = torch.full((L, L), float("-inf"), device=x.device).triu(1)
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        h = _rms(x, sd[p + "input_layernorm.weight"], eps)
+        q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(L, heads, head_dim).transpose(0, 1)
+        k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
+        v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
+        q, k = rot(q), rot(k)
+        k = k.repeat_interleave(heads // kv_heads, dim=0)
+        v = v.repeat_interleave(heads // kv_heads, dim=0)
+        a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v
+        x = x + F.linear(a.transpose(0, 1).reshape(L, heads * head_dim), sd[p + "self_attn.o_proj.weight"])
+        h = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
+        m = F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"])
+        x = x + F.linear(m, sd[p + "mlp.down_proj.weight"])
+    x = _rms(x, sd["model.norm.weight"], eps)
+    return F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"])

@@ -131,7 +131,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
                 }
-                if (OUT_F32) {
+                if (EPI == SC_EPI_SWIGLU) {
+                    // columns n..n+3 hold (gate_{j}, gate_{j+1}, up_{j}, up_{j+1}), j = n/2: write silu(gate)*up to [m][j..j+1]
+                    const float g0 = acc[mi][nj][0] + bv[0], g1 = acc[mi][nj][1] + bv[1];
+                    const float u0 = acc[mi][nj][2] + bv[2], u1 = acc[mi][nj][3] + bv[3];
+                    const sc_h2 o = {(_Float16)(g0 / (1.0f + __expf(-g0)) * u0), (_Float16)(g1 / (1.0f + __expf(-g1)) * u1)};
+                    *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+                } else if (OUT_F32) {
                     *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
                 } else {
                     sc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -166,10 +172,12 @@ extern "C" int sc_gemm_f16(const void* A, int lda, const void* W, const void* bi
     SC_REQUIRE(M > 0 && N > 0 && K > 0, "sc_gemm_f16: M, N, K must be positive");
     SC_REQUIRE(N % BN == 0, "sc_gemm_f16: N (%d) must be a multiple of %d", N, BN);
     SC_REQUIRE(K % BK == 0, "sc_gemm_f16: K (%d) must be a multiple of %d", K, BK);
-    SC_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0, "sc_gemm_f16: bad leading dimensions");
+    SC_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= (epilogue == SC_EPI_SWIGLU ? N / 2 : N) && ldc % 2 == 0 && (epilogue == SC_EPI_SWIGLU || ldc % 4 == 0),
+               "sc_gemm_f16: bad leading dimensions");
     SC_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0), "sc_gemm_f16: bad residual leading dimension");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0, "sc_gemm_f16: A and W must be 16-byte aligned");
-    SC_REQUIRE(((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0,
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0 ||
+                   (epilogue == SC_EPI_SWIGLU && (reinterpret_cast<uintptr_t>(C) & 3) == 0),
                "sc_gemm_f16: C, bias, residual must be 8-byte aligned");
     SC_REQUIRE(a_grp >= 0 && (a_grp == 0 || (a_grp_stride >= a_grp && a_grp_off >= 0)), "sc_gemm_f16: bad A row-group map");
     hipStream_t s = (hipStream_t)stream;
@@ -177,6 +185,9 @@ extern "C" int sc_gemm_f16(const void* A, int lda, const void* W, const void* bi
         case SC_EPI_NONE: return launch_gemm<SC_EPI_NONE>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
         case SC_EPI_QUICK_GELU: return launch_gemm<SC_EPI_QUICK_GELU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
         case SC_EPI_GELU_ERF: return launch_gemm<SC_EPI_GELU_ERF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, out_f32, a_grp, a_grp_stride, a_grp_off, s);
+        case SC_EPI_SWIGLU:
+            SC_REQUIRE(!residual && !out_f32, "sc_gemm_f16: SwiGLU epilogue takes no residual and writes fp16");
+            return launch_gemm<SC_EPI_SWIGLU>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, 0, a_grp, a_grp_stride, a_grp_off, s);
     }
     return sc_fail(SC_ERR_ARG, "sc_gemm_f16: unknown epilogue %d", epilogue);
 }

@@ -1,0 +1,75 @@
+// Small HBM-bound pieces of the Qwen2 path (reference llava_qwen.py:137-155 -> transformers Qwen2ForCausalLM, and the
+// embedding splice of llava_arch.py:208-343): token-embedding row gather, rotary position embedding.
+#include "sc_common.h"
+
+namespace {
+
+// out[r] = table[ids[r]]  (ids < 0 -> zeros: the -200 image sentinel rows are filled by the splice afterwards)
+__global__ __launch_bounds__(256) void k_gather_rows(const int* __restrict__ ids, const _Float16* __restrict__ table, _Float16* __restrict__ out,
+                                                     int rows, int H, int ldo, int vocab) {
+    const int per_row = H / 8;
+    const size_t total = (size_t)rows * per_row;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(g / per_row), c = (int)(g - (size_t)r * per_row) * 8;
+        const int id = ids[r];
+        sc_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (id >= 0 && id < vocab) v = *reinterpret_cast<const sc_h8*>(table + (size_t)id * H + c);
+        *reinterpret_cast<sc_h8*>(out + (size_t)r * ldo + c) = v;
+    }
+}
+
+// Rotate-half RoPE in place on `heads` heads of width Dh starting at column 0 of each row (row stride ld):
+//   x'[i] = x[i]*cos[i] - x[i+Dh/2]*sin[i];  x'[i+Dh/2] = x[i+Dh/2]*cos[i] + x[i]*sin[i],  i < Dh/2
+// cos/sin = fp16(cos/sin(pos * theta^(-2i/Dh))) as HF builds them (fp32 trig, cast to the model dtype); products and the sum
+// are rounded to fp16 like the fp16 tensor ops of apply_rotary_pos_emb.
+__global__ __launch_bounds__(256) void k_rope(_Float16* __restrict__ x, int ld, const int* __restrict__ pos, int pos0, int rows, int heads, int Dh,
+                                              float log2_theta) {
+    const int half = Dh / 2;
+    const int per_row = heads * (half / 4);            // 4 rotation pairs per thread (8-byte accesses)
+    const size_t total = (size_t)rows * per_row;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(g / per_row);
+        const int rem = (int)(g - (size_t)r * per_row);
+        const int h = rem / (half / 4), i0 = (rem - h * (half / 4)) * 4;
+        const float p = (float)(pos ? pos[r] : pos0 + r);
+        _Float16* base = x + (size_t)r * ld + h * Dh;
+        sc_h4 a = *reinterpret_cast<const sc_h4*>(base + i0);
+        sc_h4 b = *reinterpret_cast<const sc_h4*>(base + half + i0);
+        sc_h4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv_freq = exp2f(-log2_theta * (float)(2 * (i0 + e)) / (float)Dh);
+            float sn, cs;
+            sincosf(p * inv_freq, &sn, &cs);
+            const _Float16 c16 = (_Float16)cs, s16 = (_Float16)sn;
+            const _Float16 t1 = (_Float16)((float)a[e] * (float)c16), t2 = (_Float16)((float)b[e] * (float)s16);
+            const _Float16 t3 = (_Float16)((float)b[e] * (float)c16), t4 = (_Float16)((float)a[e] * (float)s16);
+            oa[e] = (_Float16)((float)t1 - (float)t2);
+            ob[e] = (_Float16)((float)t3 + (float)t4);
+        }
+        *reinterpret_cast<sc_h4*>(base + i0) = oa;
+        *reinterpret_cast<sc_h4*>(base + half + i0) = ob;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_gather_rows_f16(const int32_t* ids, const void* table, void* out, int rows, int H, int ldo, int vocab, sc_stream_t stream) {
+    SC_REQUIRE(ids && table && out, "sc_gather_rows_f16: null pointer argument");
+    SC_REQUIRE(rows > 0 && H > 0 && H % 8 == 0 && ldo >= H && ldo % 8 == 0 && vocab > 0, "sc_gather_rows_f16: bad sizes");
+    const size_t total = (size_t)rows * (H / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const _Float16*)table, (_Float16*)out, rows, H, ldo, vocab);
+    SC_CHECK_LAUNCH("sc_gather_rows_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_rope_f16(void* x, int ld, const int32_t* positions, int pos0, int rows, int heads, int Dh, float theta, sc_stream_t stream) {
+    SC_REQUIRE(x, "sc_rope_f16: null pointer argument");
+    SC_REQUIRE(rows > 0 && heads > 0 && Dh > 0 && Dh % 8 == 0 && ld >= heads * Dh && ld % 4 == 0 && theta > 1.f, "sc_rope_f16: bad sizes");
+    const size_t total = (size_t)rows * heads * (Dh / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rope, dim3(grid), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, ld, positions, pos0, rows, heads, Dh, log2f(theta));
+    SC_CHECK_LAUNCH("sc_rope_f16");
+    return SC_OK;
+}

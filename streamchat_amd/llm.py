@@ -1,0 +1,223 @@
+"""LongVA-7B language side on hand-written gfx950 kernels: Qwen2 decoder with a KV cache, the `<image>` embedding
+splice and `generate_with_image_embedding`.
+
+Mirrors the reference seams `LlavaQwenForCausalLM.generate_with_image_embedding` (longva/model/language_model/
+llava_qwen.py:137-155) and `LlavaMetaForCausalLM.prepare_inputs_embeddings_for_multimodal` (longva/model/llava_arch.py:
+208-343) for the single-sequence case the streaming path uses.  The reference calls HF `generate(..., use_cache=False)`,
+re-running the full 26k-49k-token prefill for EVERY generated token (inference_streaming_longva_v2.py:257,
+utiles.py:556,605); here the prompt is prefilled once into a resident KV cache and each new token is one decode step
+(greedy outputs are identical with and without a cache — SURVEY.md Appendix D)."""
+import types
+
+import torch
+
+from . import ops
+
+IMAGE_TOKEN_INDEX = -200
+IGNORE_INDEX = -100
+
+
+class Qwen2ConfigLite:
+    def __init__(self, hidden=3584, layers=28, heads=28, kv_heads=4, intermediate=18944, vocab=152064, eps=1e-6, rope_theta=1e6,
+                 head_dim=None, tokenizer_model_max_length=None):
+        self.hidden, self.layers, self.heads, self.kv_heads = hidden, layers, heads, kv_heads
+        self.intermediate, self.vocab, self.eps, self.rope_theta = intermediate, vocab, eps, rope_theta
+        self.head_dim = head_dim or hidden // heads
+        self.tokenizer_model_max_length = tokenizer_model_max_length
+        self.mm_use_im_start_end = False            # LongVA config; the True branch of the prompt code is dead (Q18)
+
+
+QWEN2_7B = dict(hidden=3584, layers=28, heads=28, kv_heads=4, intermediate=18944, vocab=152064, rope_theta=1e6)
+
+
+def random_qwen2_state_dict(cfg: Qwen2ConfigLite, seed=0, device="cuda", dtype=torch.float16, std=0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s: (torch.randn(*s, device=device, generator=g) * std).to(dtype)
+    H, I, dq, dkv = cfg.hidden, cfg.intermediate, cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+    sd = {"model.embed_tokens.weight": rn(cfg.vocab, H), "model.norm.weight": 1 + rn(H), "lm_head.weight": rn(cfg.vocab, H)}
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = rn(dq, H); sd[p + "self_attn.q_proj.bias"] = rn(dq)
+        sd[p + "self_attn.k_proj.weight"] = rn(dkv, H); sd[p + "self_attn.k_proj.bias"] = rn(dkv)
+        sd[p + "self_attn.v_proj.weight"] = rn(dkv, H); sd[p + "self_attn.v_proj.bias"] = rn(dkv)
+        sd[p + "self_attn.o_proj.weight"] = rn(H, dq)
+        sd[p + "mlp.gate_proj.weight"] = rn(I, H); sd[p + "mlp.up_proj.weight"] = rn(I, H); sd[p + "mlp.down_proj.weight"] = rn(H, I)
+        sd[p + "input_layernorm.weight"] = 1 + rn(H); sd[p + "post_attention_layernorm.weight"] = 1 + rn(H)
+    return sd
+
+
+def _h(t, device):
+    return t.detach().to(device=device, dtype=torch.float16).contiguous()
+
+
+class Qwen2Model:
+    """Decoder stack + lm_head on the HIP kernels, with a contiguous per-layer KV cache [max_seq, 2*Hkv*Dh] (K | V)."""
+
+    def __init__(self, state_dict, cfg: Qwen2ConfigLite, device="cuda", max_seq=65536, consume=False):
+        self.cfg, self.device, self.max_seq = cfg, torch.device(device), max_seq
+        H, I, Dh = cfg.hidden, cfg.intermediate, cfg.head_dim
+        if H % 128 or I % 128 or (cfg.heads * Dh) % 128 or (2 * cfg.kv_heads * Dh) % 128 or cfg.vocab % 128 or Dh not in (32, 64, 128):
+            raise ValueError("HIP Qwen2 path needs 128-multiple widths and head_dim in {32, 64, 128}")
+        sd = state_dict
+        take = (lambda k: _h(sd.pop(k), device)) if consume else (lambda k: _h(sd[k], device))
+        self.embed = take("model.embed_tokens.weight")
+        self.norm = take("model.norm.weight")
+        self.lm_head = take("lm_head.weight") if "lm_head.weight" in sd else self.embed
+        self.L = []
+        for i in range(cfg.layers):
+            p = f"model.layers.{i}."
+            g, u = take(p + "mlp.gate_proj.weight"), take(p + "mlp.up_proj.weight")
+            wgu = torch.cat([g.view(I // 2, 2, H), u.view(I // 2, 2, H)], dim=1).reshape(2 * I, H).contiguous()   # (g g u u) interleave
+            del g, u
+            self.L.append(dict(
+                wq=take(p + "self_attn.q_proj.weight"), bq=take(p + "self_attn.q_proj.bias"),
+                wkv=torch.cat([take(p + "self_attn.k_proj.weight"), take(p + "self_attn.v_proj.weight")]).contiguous(),
+                bkv=torch.cat([take(p + "self_attn.k_proj.bias"), take(p + "self_attn.v_proj.bias")]).contiguous(),
+                wo=take(p + "self_attn.o_proj.weight"), wgu=wgu, wd=take(p + "mlp.down_proj.weight"),
+                ln1=take(p + "input_layernorm.weight"), ln2=take(p + "post_attention_layernorm.weight")))
+        self.cache = None
+        self.cache_len = 0
+        self._buf_rows = 0
+
+    def embed_tokens(self, ids):
+        return ops.gather_rows(ids.to(self.device).view(-1), self.embed)
+
+    def reset_cache(self, max_seq=None):
+        c = self.cfg
+        if max_seq is not None:
+            self.max_seq = max_seq
+        if self.cache is None or self.cache[0].shape[0] < self.max_seq:
+            self.cache = [torch.empty((self.max_seq, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=self.device)
+                          for _ in range(c.layers)]
+        self.cache_len = 0
+
+    def _buffers(self, n):
+        if self._buf_rows < n:
+            c, e = self.cfg, lambda *s: torch.empty(*s, dtype=torch.float16, device=self.device)
+            self._b = dict(x=e(n, c.hidden), q=e(n, c.heads * c.head_dim), att=e(n, c.heads * c.head_dim), h2=e(n, c.hidden),
+                           m=e(n, c.intermediate), h=e(n, c.hidden))
+            self._buf_rows = n
+        return self._b
+
+    def forward(self, embeds, last_only=True):
+        """Append `embeds` [n, H] at positions cache_len.. (prefill chunk or one decode token).  Returns fp32 logits of the last
+        row ([vocab]) or of every row ([n, vocab]) and advances the cache."""
+        c = self.cfg
+        if self.cache is None:
+            self.reset_cache()
+        n, pos0 = embeds.shape[0], self.cache_len
+        if pos0 + n > self.max_seq:
+            raise ValueError(f"sequence {pos0 + n} exceeds the KV cache ({self.max_seq})")
+        B = self._buffers(n)
+        dq, dkv, Dh = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim
+        h = B["h"][:n]
+        h.copy_(embeds)
+        h2 = B["h2"][:n]
+        S = pos0 + n
+        for l, L in enumerate(self.L):
+            x = ops.rmsnorm(h, L["ln1"], c.eps, out=B["x"][:n])
+            q = ops.gemm(x, L["wq"], L["bq"], out=B["q"][:n])
+            kv = ops.gemm(x, L["wkv"], L["bkv"], out=self.cache[l][pos0:S])
+            ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
+            ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)                       # K occupies columns [0, dkv) of the cache row
+            ck = self.cache[l][:S]
+            att = ops.attention(q.unsqueeze(0), ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.heads, c.kv_heads, Dh, Dh ** -0.5,
+                                causal=True, out=B["att"][:n].unsqueeze(0)).squeeze(0)
+            ops.gemm(att, L["wo"], None, residual=h, out=h2)
+            x = ops.rmsnorm(h2, L["ln2"], c.eps, out=B["x"][:n])
+            m = ops.gemm(x, L["wgu"], None, epilogue="swiglu", out=B["m"][:n])
+            ops.gemm(m, L["wd"], None, residual=h2, out=h)
+        self.cache_len = S
+        tail = h[n - 1:n] if last_only else h
+        xn = ops.rmsnorm(tail, self.norm, c.eps)
+        logits = ops.gemm(xn, self.lm_head, None, out_f32=True)
+        return logits[0] if last_only else logits
+
+
+def splice_image_embeddings(ids, embed_table, image_features, max_len=None, labels=None):
+    """llava_arch.py:208-343 for one sequence: text ids -> embedding rows, every -200 sentinel replaced by the next tensor of
+    `image_features`; zero sentinels => the visual tokens are dropped (:247-254, Q18); truncated to max_len (:288-291)."""
+    dev = embed_table.device
+    ids = ids.to(dev)
+    pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+    feats = [f.reshape(-1, f.shape[-1]) for f in (image_features or [])]
+    n_img_rows = sum(feats[i].shape[0] for i in range(len(pos)))
+    total = ids.numel() - len(pos) + n_img_rows
+    out = torch.empty((total, embed_table.shape[1]), dtype=torch.float16, device=dev)
+    labels_out = torch.full((total,), IGNORE_INDEX, dtype=torch.long, device=dev)
+    emb = ops.gather_rows(ids, embed_table)          # one gather for all text rows (sentinel ids < 0 give zero rows)
+    src, dst = 0, 0
+    for k, p in enumerate(pos + [ids.numel()]):
+        seg = p - src
+        out[dst:dst + seg] = emb[src:src + seg]
+        if labels is not None:
+            labels_out[dst:dst + seg] = labels.to(dev)[src:src + seg]
+        dst += seg
+        src = p + 1
+        if k < len(pos):
+            f = feats[k].to(dev, torch.float16)
+            out[dst:dst + f.shape[0]] = f
+            dst += f.shape[0]
+    if max_len is not None:
+        out, labels_out = out[:max_len], labels_out[:max_len]
+    return out, labels_out
+
+
+class LlavaQwenForCausalLM:
+    """Mirror of the reference model object the entry point drives (longva/model/language_model/llava_qwen.py:40-155 +
+    LlavaMetaForCausalLM): `.encode_images`, `.get_model().embed_tokens`, `.prepare_inputs_embeddings_for_multimodal`,
+    `.generate_with_image_embedding`, `.config`, `.device`."""
+
+    def __init__(self, lm: Qwen2Model, frame_encoder=None, eos_token_id=None):
+        self.lm, self.frame_encoder = lm, frame_encoder
+        self.config = lm.cfg
+        self.device = lm.device
+        self.eos_token_id = eos_token_id
+        self.training = False
+
+    def get_model(self):
+        return types.SimpleNamespace(embed_tokens=self.lm.embed_tokens, mm_projector=getattr(self.frame_encoder, "projector", None))
+
+    def encode_images(self, images):
+        return self.frame_encoder.encode_images(images)
+
+    def encode_frames_u8(self, frames):
+        return self.frame_encoder.encode_frames_u8(frames)
+
+    def prepare_inputs_embeddings_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, image_features,
+                                                 modalities=["image"]):
+        """llava_arch.py:208-343 for batch size 1: text ids -> embed_tokens rows, every -200 sentinel replaced by the next tensor of
+        `image_features`; zero sentinels => visual tokens dropped (:247-254, Q18); truncated to tokenizer_model_max_length (:288-291).
+        Returns the reference's 6-tuple (None, position_ids, attention_mask, past_key_values, inputs_embeds [1, L, H], labels)."""
+        ids = input_ids[0] if input_ids.dim() == 2 else input_ids
+        if attention_mask is not None:
+            ids = ids[attention_mask[0].bool()] if attention_mask.dim() == 2 else ids[attention_mask.bool()]
+        lab = None if labels is None else (labels[0] if labels.dim() == 2 else labels)
+        out, labels_out = splice_image_embeddings(ids, self.lm.embed, image_features, self.config.tokenizer_model_max_length, lab)
+        L = out.shape[0]
+        new_pos = None if position_ids is None else torch.arange(L, device=self.device).unsqueeze(0)
+        new_mask = None if attention_mask is None else torch.ones((1, L), dtype=attention_mask.dtype, device=self.device)
+        return None, new_pos, new_mask, past_key_values, out.unsqueeze(0), (None if labels is None else labels_out.unsqueeze(0))
+
+    @torch.no_grad()
+    def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=False, temperature=1.0,
+                                      top_p=None, num_beams=1, max_new_tokens=256, use_cache=True, generator=None, **kwargs):
+        """llava_qwen.py:137-155 -> Qwen2 generate(inputs_embeds=...).  Returns the NEW token ids [1, n] like HF does for
+        inputs_embeds prompts.  `use_cache` is accepted for call compatibility; a KV cache is always used."""
+        if image_embeddings is not None or True:
+            _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
+        self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
+        logits = self.lm.forward(embeds[0])
+        new = []
+        for step in range(max_new_tokens):
+            if do_sample and temperature > 0:
+                probs = torch.softmax(logits / temperature, dim=-1)
+                tok = int(torch.multinomial(probs, 1, generator=generator).item())
+            else:
+                tok = int(torch.argmax(logits).item())
+            new.append(tok)
+            if self.eos_token_id is not None and tok == self.eos_token_id:
+                break
+            if step + 1 < max_new_tokens:
+                logits = self.lm.forward(self.lm.embed_tokens(torch.tensor([tok], device=self.device)))
+        return torch.tensor([new], dtype=torch.long, device=self.device)

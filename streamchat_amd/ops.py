@@ -194,7 +194,7 @@ def sim_topk(q: torch.Tensor, docs: torch.Tensor, k: int = 1, metric: str = "cos
 # ------------------------------------------------------------------------------------------------
 # dense blocks (MFMA GEMM + norms)
 # ------------------------------------------------------------------------------------------------
-EPI = {"none": 0, "quick_gelu": 1, "gelu": 2}
+EPI = {"none": 0, "quick_gelu": 1, "gelu": 2, "swiglu": 3}
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False,
@@ -212,7 +212,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
     if K2 != K or a.stride(1) != 1 or not w.is_contiguous():
         raise StreamChatHipError("gemm: shape/stride mismatch")
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.float16, device=a.device)
+        out = torch.empty((M, N // 2 if epilogue == "swiglu" else N), dtype=torch.float32 if out_f32 else torch.float16, device=a.device)
     if out.stride(1) != 1 or (residual is not None and residual.stride(1) != 1):
         raise StreamChatHipError("gemm: out/residual must be row-major")
     from ctypes import c_void_p
@@ -328,3 +328,30 @@ def pool(hidden, lengths=None, mode: str = "cls", normalize: bool = False):
         check(lib.sc_pool_f16(ptr(hidden), ptr(ln), ptr(out), B, L, H, 0 if mode == "cls" else 1, 1 if normalize else 0,
                               stream_ptr(hidden.device)), "sc_pool_f16")
     return out
+
+
+def gather_rows(ids, table, out=None):
+    """out[r] = table[ids[r]] (fp16 rows; negative ids give zero rows)."""
+    _require_cuda(ids, table)
+    lib = _lib.load()
+    ids = ids.to(torch.int32).contiguous().view(-1)
+    rows, H = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((rows, H), dtype=torch.float16, device=table.device)
+    from ctypes import c_void_p
+    with torch.cuda.device(table.device):
+        check(lib.sc_gather_rows_f16(ptr(ids), ptr(table), c_void_p(out.data_ptr()), rows, H, out.stride(0), table.shape[0],
+                                     stream_ptr(table.device)), "sc_gather_rows_f16")
+    return out
+
+
+def rope_(x, heads: int, Dh: int, theta: float, pos0: int = 0, positions=None):
+    """in-place rotate-half RoPE on x [rows, >= heads*Dh] (row-strided view allowed)."""
+    _require_cuda(x)
+    lib = _lib.load()
+    from ctypes import c_void_p
+    pos = None if positions is None else positions.to(device=x.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(x.device):
+        check(lib.sc_rope_f16(c_void_p(x.data_ptr()), x.stride(0), ptr(pos), pos0, x.shape[0], heads, Dh, c_float(theta),
+                              stream_ptr(x.device)), "sc_rope_f16")
+    return x

@@ -1,0 +1,97 @@
+"""GPU: HIP Qwen2 (prefill + KV-cache decode), the `<image>` splice and generate_with_image_embedding against the golden
+vectors of the real HF Qwen2ForCausalLM (tiny config) / the reference's own splice function, and the fp32 PyTorch
+restatement at Qwen2-7B widths.  Tolerance on logits: fp16 storage + fp32 accumulate -> 3e-2 of the max |logit|;
+greedy token ids must match exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from streamchat_amd import llm as LM, ops
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _tiny():
+    d = np.load(os.path.join(G, "qwen2_tiny.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("lm.")}
+    cfg = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=512, rope_theta=1e6)
+    return d, sd, cfg
+
+
+def test_prefill_logits_vs_hf_golden():
+    d, sd, cfg = _tiny()
+    lm = LM.Qwen2Model(sd, cfg, max_seq=128)
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    logits = lm.forward(emb, last_only=False)
+    ref = torch.from_numpy(d["logits"]).cuda()
+    assert logits.shape == ref.shape and logits.dtype == torch.float32
+    assert (logits - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
+    assert lm.cache_len == 37
+
+
+def test_chunked_prefill_and_decode_match_full_prefill():
+    """KV-cache correctness: prefill(20) + prefill(16) + decode(1) == one 37-token prefill (same kernels, same rounding)."""
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    a = LM.Qwen2Model(sd, cfg, max_seq=64)
+    full = a.forward(emb)
+    b = LM.Qwen2Model(sd, cfg, max_seq=64)
+    b.forward(emb[:20]); b.forward(emb[20:36])
+    last = b.forward(emb[36:37])
+    torch.testing.assert_close(last, full, rtol=2e-3, atol=2e-3)
+    assert int(last.argmax()) == int(full.argmax())
+
+
+def test_greedy_generation_matches_hf():
+    d, sd, cfg = _tiny()
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, max_seq=64))
+    # drive generate through the splice: ids = [<image>] only, image_embeddings = the golden inputs_embeds
+    out = model.generate_with_image_embedding(torch.tensor([[-200]]), image_embeddings=[torch.from_numpy(d["inputs_embeds"]).cuda().half()],
+                                              modalities=["video"], do_sample=False, max_new_tokens=8, use_cache=False)
+    assert out.shape == (1, 8)
+    assert out[0].cpu().tolist() == d["greedy"].tolist()
+
+
+def test_splice_matches_reference():
+    d = np.load(os.path.join(G, "splice.npz"))
+    table = torch.from_numpy(d["table"]).cuda().half()
+    feats = torch.from_numpy(d["feats"]).cuda().half()
+    for k in ("middle", "start", "none", "truncated", "end"):
+        mx = int(d[k + ".max_len"])
+        out, _ = LM.splice_image_embeddings(torch.from_numpy(d[k + ".ids"]), table, [feats], None if mx < 0 else mx)
+        ref = torch.from_numpy(d[k + ".embeds"]).cuda().half()          # fp16 rounding of the fp32 golden rows is exact data movement
+        assert torch.equal(out, ref), k
+
+
+def test_rope_and_swiglu_kernels_vs_torch():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(50, 4 * 128, device="cuda", generator=g).half()
+    y = ops.rope_(x.clone(), 4, 128, 1e6, pos0=1000)
+    pos = torch.arange(1000, 1050, device="cuda", dtype=torch.float32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2, device="cuda", dtype=torch.float32) / 128))
+    fr = torch.outer(pos, inv)
+    cos, sin = torch.cat([fr, fr], -1).cos()[:, None], torch.cat([fr, fr], -1).sin()[:, None]
+    xf = x.float().view(50, 4, 128)
+    ref = xf * cos + torch.cat([-xf[..., 64:], xf[..., :64]], -1) * sin
+    torch.testing.assert_close(y.float().view(50, 4, 128), ref, rtol=4e-3, atol=4e-3)
+    a = torch.randn(70, 256, device="cuda", generator=g).half()
+    wg, wu = (torch.randn(384, 256, device="cuda", generator=g) / 16).half(), (torch.randn(384, 256, device="cuda", generator=g) / 16).half()
+    wgu = torch.cat([wg.view(192, 2, 256), wu.view(192, 2, 256)], 1).reshape(768, 256).contiguous()
+    out = ops.gemm(a, wgu, epilogue="swiglu")
+    ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    torch.testing.assert_close(out.float(), ref, rtol=3e-3, atol=3e-3)
+
+
+def test_qwen2_7b_width_layers_vs_torch_fp32():
+    """2 layers at the real Qwen2-7B widths (3584 / 28 q-heads / 4 kv-heads / 18944) on 300 tokens vs fp32 PyTorch."""
+    cfg = LM.Qwen2ConfigLite(**dict(LM.QWEN2_7B, layers=2, vocab=1024))
+    sd = LM.random_qwen2_state_dict(cfg, seed=5)
+    lm = LM.Qwen2Model(sd, cfg, max_seq=512)
+    emb = (torch.randn(300, 3584, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.5).half()
+    logits = lm.forward(emb, last_only=False)
+    ref = R.qwen2_logits({k: v.float() for k, v in sd.items()}, emb.float(), heads=28, kv_heads=4, layers=2, head_dim=128)
+    assert (logits - ref).abs().max().item() < 3e-2 * ref.abs().max().item()

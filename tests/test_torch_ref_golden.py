@@ -46,3 +46,18 @@ def test_tokenizer_image_token_vs_reference():
             return types.SimpleNamespace(input_ids=([s.bos_token_id] + ids) if s.bos_token_id is not None else ids)
     for c in json.load(open(os.path.join(G, "tokenizer_image_token.json"))):
         assert tokenizer_image_token(c["prompt"], Tok(c["bos"]), -200) == c["ids"]
+
+
+def test_qwen2_vs_hf():
+    d = np.load(os.path.join(G, "qwen2_tiny.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("lm.")}
+    lg = R.qwen2_logits(sd, torch.from_numpy(d["inputs_embeds"]), heads=4, kv_heads=2, layers=2, head_dim=64)
+    torch.testing.assert_close(lg, torch.from_numpy(d["logits"]), rtol=1e-4, atol=1e-4)
+    # greedy continuation with the oracle reproduces HF generate()
+    emb = torch.from_numpy(d["inputs_embeds"])
+    toks = []
+    for _ in range(8):
+        t = int(R.qwen2_logits(sd, emb, heads=4, kv_heads=2, layers=2, head_dim=64)[-1].argmax())
+        toks.append(t)
+        emb = torch.cat([emb, sd["model.embed_tokens.weight"][t][None]])
+    assert toks == d["greedy"].tolist()

@@ -420,6 +420,40 @@ def gen_memory():
               open(os.path.join(OUT, "memory_search.json"), "w"))
 
 
+# ------------------------------------------------------------------------------------------
+# G7  embedding splice: LlavaMetaForCausalLM.prepare_inputs_embeddings_for_multimodal
+# (longva/model/llava_arch.py:208-343), imported with package stubs.
+# ------------------------------------------------------------------------------------------
+def gen_splice():
+    for name in ["longva", "longva.model", "longva.model.language_model", "longva.model.multimodal_resampler"]:
+        m = types.ModuleType(name); m.__path__ = [REF + "/" + name.replace(".", "/")]; sys.modules[name] = m
+    q = types.ModuleType("longva.model.multimodal_resampler.qformer"); q.Qformer = type("Qformer", (), {}); sys.modules[q.__name__] = q
+    from longva.model.llava_arch import LlavaMetaForCausalLM
+    torch.manual_seed(3)
+    table = torch.nn.Embedding(50, 16)
+    table.weight.data = torch.randn(50, 16)
+
+    class Shim(LlavaMetaForCausalLM):
+        def __init__(self, max_len):
+            self.config = types.SimpleNamespace(tokenizer_model_max_length=max_len, tune_mm_mlp_adapter=False, mm_use_im_start_end=False,
+                                                tokenizer_padding_side="right", use_pos_skipping=False)
+            self.device = torch.device("cpu"); self.training = False
+
+        def get_model(self):
+            return types.SimpleNamespace(embed_tokens=table)
+    cases = {}
+    feats = torch.randn(7, 16)
+    specs = {"middle": ([3, 9, -200, 4, 4, 12], None), "start": ([-200, 5, 6], None), "none": ([1, 2, 3, 4], None),
+             "truncated": ([3, 9, -200, 4, 4, 12], 6), "end": ([8, 8, -200], None)}
+    for k, (ids, mx) in specs.items():
+        out = Shim(mx).prepare_inputs_embeddings_for_multimodal(torch.tensor([ids]), None, None, None, None, [feats], ["video"])
+        assert out[0] is None and out[1] is None and out[2] is None and out[5] is None
+        cases[k + ".ids"] = np.asarray(ids, np.int64)
+        cases[k + ".max_len"] = np.asarray(-1 if mx is None else mx)
+        cases[k + ".embeds"] = out[4][0].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "splice.npz"), table=table.weight.detach().numpy(), feats=feats.numpy(), **cases)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: golden vectors can only be generated in the authoring container")
@@ -434,6 +468,7 @@ def main():
         gen_tree(ns)
         gen_search(ns)
         gen_memory()
+        gen_splice()
     print(f"wrote {n} k-means cases + forgetting/tree/search fixtures to {os.path.normpath(OUT)}")
     meta = dict(torch=torch.__version__, numpy=np.__version__, reference="hmxiong/StreamChat @ 2025-03-14",
                 functions=sorted(WANT))

@@ -67,10 +67,35 @@ def gen_bert():
     np.savez_compressed(os.path.join(OUT, "bert_tiny.npz"), **d)
 
 
+def gen_qwen2():
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    torch.manual_seed(2)
+    cfg = Qwen2Config(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False)
+    m = Qwen2ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn_like(p) * (0.3 if "embed" in n else 0.8 / p.shape[-1] ** 0.5))
+            else:
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if "norm" in n else 0.0))
+    emb = torch.randn(1, 37, 256) * 0.5
+    with torch.no_grad():
+        logits = m(inputs_embeds=emb).logits[0]
+        gen = m.generate(inputs_embeds=emb, max_new_tokens=8, do_sample=False, use_cache=True)
+        gen_nc = m.generate(inputs_embeds=emb, max_new_tokens=8, do_sample=False, use_cache=False)
+    assert torch.equal(gen, gen_nc)        # cache vs no-cache greedy outputs agree
+    d = {"inputs_embeds": emb[0].numpy(), "logits": logits.numpy(), "greedy": gen[0].numpy(), "cfg": np.asarray([4, 2, 2, 64])}
+    for k, v in m.state_dict().items():
+        d["lm." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "qwen2_tiny.npz"), **d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("authoring container only")
     torch.set_num_threads(1)
     gen_clip()
     gen_bert()
-    print("transformers", transformers.__version__, "-> clip_tiny.npz bert_tiny.npz")
+    gen_qwen2()
+    print("transformers", transformers.__version__, "-> clip_tiny.npz bert_tiny.npz qwen2_tiny.npz")
