@@ -21,7 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from streamchat_amd import ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
+from streamchat_amd import llm as LM, ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
 from streamchat_amd.memory_bank.memory_retrieval import local_doc_qa as Q   # noqa: E402
 
 FRAMES = 1024
@@ -38,12 +38,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-llm", action="store_true", help="C2 workload: stop after retrieval (no 7B prefill)")
+    ap.add_argument("--decode-tokens", type=int, default=8, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     return ap.parse_args()
 
 
 class Pipeline:
-    def __init__(self, device, n_frames, seed):
+    def __init__(self, device, n_frames, seed, with_llm=True):
         cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
         self.cfg = cfg
         self.sd_vit = V.random_clip_state_dict(cfg, seed=0, device=device)
@@ -62,6 +64,14 @@ class Pipeline:
         self.docs = [Q.Document(f"Conversation content on 2024-05-{1 + i // 8:02d}:[|User|]: {synthetic.caption(100 + i, words=8)}; "
                                 f"[|AI|]: {synthetic.caption(200 + i, words=10)}", {"source": f"2024-05-{1 + i // 8:02d}"}) for i in range(32)]
         self.question = "where did I leave the red cup and what was on the kitchen table"
+        self.model = None
+        if with_llm:        # LongVA-7B language side: Qwen2-7B shape, random-init fp16 (15 GB), KV cache for 64k tokens
+            qc = LM.Qwen2ConfigLite(**LM.QWEN2_7B)
+            sd = LM.random_qwen2_state_dict(qc, seed=4, device=device)
+            self.model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, qc, device=device, max_seq=53248, consume=True), self.enc)
+            del sd
+            torch.cuda.empty_cache()
+        self.llm_tok = synthetic.SyntheticTokenizer()
 
     def step(self):
         # ---- encode ----
@@ -81,7 +91,32 @@ class Pipeline:
         path_feats, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, short_emb, self.colbert, self.tok,
                                                                               cache=U.CaptionEmbeddingCache())
         self.last = dict(tree=tree, short=short, related=related, path_text=path_text, path_feats=path_feats)
+        # ---- answer-time 7B prefill over [short | long] frame tokens + prompt (first answer token) ----
+        if self.model is not None:
+            long_emb = torch.cat([t.reshape(-1, t.shape[-1]) for t in path_feats], dim=0)
+            image_embeddings = torch.cat([short_emb, long_emb], dim=0)
+            qs = S.build_answer_prompt(self.question, path_text[-1], None)
+            conv = S.conv_templates["qwen_1_5"].copy()
+            conv.append_message(conv.roles[0], qs)
+            conv.append_message(conv.roles[1], None)
+            from streamchat_amd.mm_utils import tokenizer_image_token
+            ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
+            out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
+                                                           max_new_tokens=1)
+            self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
         return self.last
+
+    def decode_rate(self, n_tokens):
+        """greedy decode tokens/s on the context left in the KV cache by the last step (reported separately from the metric)"""
+        lm = self.model.lm
+        tok = int(self.last["first_token"][0, 0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_tokens):
+            logits = lm.forward(lm.embed_tokens(torch.tensor([tok], device=self.device)))
+            tok = int(torch.argmax(logits).item())
+        torch.cuda.synchronize()
+        return n_tokens / (time.perf_counter() - t0)
 
 
 def cpu_baseline(pipe, n_cpu_frames):
@@ -126,7 +161,7 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    pipe = Pipeline(dev, a.frames, seed=1234 + rank)
+    pipe = Pipeline(dev, a.frames, seed=1234 + rank, with_llm=not a.no_llm)
 
     def barrier():
         if world > 1:
@@ -161,13 +196,19 @@ def main():
     if "kmeans_fit" in prof:
         kn, kms, kw = prof["kmeans_fit"]
         stages["kmeans_fit"]["note"] = "whole Lloyd fit (assign+update per iteration)"
-    out = dict(metric="frames/sec end-to-end (encode+select+retrieve), 1024-frame stream", value=round(value, 2), unit="frames/s",
+    full = not a.no_llm
+    out = dict(metric="frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
+               "frames/sec end-to-end (encode+select+retrieve), 1024-frame stream", value=round(value, 2), unit="frames/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="f16", data="synthetic",
-               config=dict(workload="C2: 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, "
-                                    "memory update (chunk 40, K 5, interval 10: one k-means T=400) + top-k retrieval; 7B prefill not yet in the timed region",
+               config=dict(workload=("C3" if full else "C2") + ": 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, "
+                                    "memory update (chunk 40, K 5, interval 10: one k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval"
+                                    + (", LongVA-7B (Qwen2-7B shape) prefill of the retrieved context + first token" if full else ""),
+                           context_tokens=pipe.last.get("context"),
                            frames_per_gpu=a.frames, micro_batch=64, parallelism=f"dp{world}", weights="random-init"),
                roofline=roof, stages=stages)
+    if full and a.decode_tokens > 0:
+        out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames)
     print(json.dumps(out))

@@ -97,3 +97,53 @@ def updating_memory_buffer(buffer_cache, long_memory_tree, summarizer_model, sum
                                                                    long_memory_tree)
     assert len(short_memory_buffer) > 0, "No memory ?"
     return long_memory_tree, short_memory_buffer
+
+
+def build_answer_prompt(question, most_fine_grad_text, history_prompt, mm_use_im_start_end=False):
+    """Prompt branches of longva_inference_with_embedding_multi_modal (:197-228, Q18): with history AND a retrieved caption the
+    `<image>` sentinel sits inside the instruction sentence; with no history the caption is ignored and the prompt is
+    `<image>\n{question}{notion}`; with history but no caption there is NO `<image>` (visual tokens are dropped by the splice)."""
+    prm = ("In addition, the text caption memory information articles most relevant to the current problem is '{most_fine_grad_text}'. \
+        The image information you currently see and recall in the {image_token} is equally important as the contextual information mentioned earlier. \
+        Sometimes the contextual information does not contain a direct answer to the question. \
+        You need to synthesize this information and give an answer to the following question:")
+    notion = "DO NOT OUTPUT ANY EXPLANATORY TEXT THAT IS UNCERTAIN ABOUT THE CURRENT QUESTION."
+    img = (DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN) if mm_use_im_start_end else DEFAULT_IMAGE_TOKEN
+    if history_prompt is not None:
+        if most_fine_grad_text is not None:
+            return history_prompt + prm.format(most_fine_grad_text=most_fine_grad_text, image_token=DEFAULT_IMAGE_TOKEN) + "\n" + question + notion
+        return history_prompt + "\n" + question + notion
+    return img + "\n" + question + notion
+
+
+def longva_inference_with_embedding_multi_modal(question, num_frames, conv_mode, model, embedding_model, tokenizer, embedding_tokenizer, chat,
+                                                short_memory_buffer_cache, long_memory_tree_cache, history_prompt=None, temperature=0.2,
+                                                top_p=None, num_beams=1, max_new_tokens=256, search_cache=None):
+    """Mirror of :164-264: retrieve long-term memory for the question, concatenate [short | long] frame tokens, build the prompt,
+    tokenise with the -200 sentinel, generate.  Returns (text, process_time, generate_time) like upstream; `temperature` etc. are
+    explicit (upstream reads the global `args`)."""
+    import time
+    from .mm_utils import tokenizer_image_token
+    short_memory_embedding = U.cat_frames(short_memory_buffer_cache).view(-1, short_memory_buffer_cache[0].shape[-1])
+    time_0 = time.time()
+    if long_memory_tree_cache is not None:
+        long_memory_list, long_memory_text_list = U.fast_search_tree_multi_modal_with_embedding(
+            long_memory_tree_cache, question, short_memory_embedding, embedding_model, embedding_tokenizer, cache=search_cache)
+        long_memory_embeddings = torch.cat([t.reshape(-1, t.shape[-1]) for t in long_memory_list], dim=0)
+        most_fine_grad_text = long_memory_text_list[-1]
+        image_embeddings = torch.cat([short_memory_embedding, long_memory_embeddings], dim=0)
+    else:
+        image_embeddings, most_fine_grad_text = short_memory_embedding, None
+    qs = build_answer_prompt(question, most_fine_grad_text, history_prompt, getattr(model.config, "mm_use_im_start_end", False))
+    conv = conv_templates[conv_mode].copy()
+    conv.append_message(conv.roles[0], qs)
+    conv.append_message(conv.roles[1], None)
+    input_ids = tokenizer_image_token(conv.get_prompt(), tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0)
+    time_1 = time.time()
+    with torch.inference_mode():
+        output_ids = model.generate_with_image_embedding(input_ids, image_embeddings=[image_embeddings], modalities=["video"],
+                                                         do_sample=True if temperature > 0 else False, temperature=temperature, top_p=top_p,
+                                                         num_beams=num_beams, max_new_tokens=max_new_tokens, use_cache=False)
+    outputs = tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+    time_2 = time.time()
+    return outputs, time_1 - time_0, time_2 - time_1
