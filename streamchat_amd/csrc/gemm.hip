@@ -16,6 +16,8 @@
 // 4 consecutive output columns of one row: bias / activation / residual / fp16 pack happen in
 // registers and leave as 8-byte stores.
 #include "sc_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -148,9 +150,219 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2: 256x256 block tile, 8 waves (2 x 4, each 128x64 = 8x4 MFMA fragments, 128 accumulator VGPRs), K consumed in 32-deep
+// steps through a 4-slot LDS ring (4 x (A 16 KiB + W 16 KiB) = 128 KiB, one workgroup per CU).
+//   * LDS-DMA (16-byte global_load_lds) of step k+3 is issued right after the ONE barrier of step k — the barrier that
+//     (a) publishes step k+1 (every wave did a counted `s_waitcnt vmcnt(4)` for its own share first: never vmcnt(0) in the
+//     steady state) and (b) proves nobody still reads slot (k+3)&3 = (k-1)&3.  Raw s_barrier: __syncthreads() would drain
+//     the DMA queue.
+//   * register pipelining: all 12 fragments of step k+1 are read while the second MFMA cluster of step k runs, into a
+//     second register set (sets ping-pong between steps: no copies); the 12 ds_read_b128 and 4 DMA issues are interleaved
+//     one-per-MFMA with sched_group_barrier, so a wave never sits in a load-issue burst while its SIMD's matrix pipe idles
+//     (PMC before: MFMA pipe 56 % busy with both waves of a SIMD issuing loads right after the barrier).
+//   * LDS rows are 64 B (4 granules); granule g of row r sits at r*64 + ((g ^ F[(r>>2)&3]) << 4), F = {0,2,3,1}:
+//     conflict-free for the 16-lane service groups of ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * tile order: XCD-contiguous chunks, inside a chunk groups of GM = 8 tile-rows with the row index fastest.
+// Measured (random operands): 1.09-1.18 PF at K >= 3584, 0.71-0.83 PF at K = 1024 (prologue/epilogue share).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
+constexpr int HALF2 = BM2 * BK2 * 2;            // 16 KiB per operand per stage
+constexpr int STAGE2 = 2 * HALF2;               // 32 KiB
+constexpr int NSTAGE2 = 4;
+
+__device__ __forceinline__ int swzF(int x) { return (0x78 >> (2 * (x & 3))) & 3; }
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                    const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                    void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
+                                                    int a_grp_stride, int a_grp_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // grouped raster: GM tile-rows per group, tile-row index fastest, so the ~32 tiles an XCD runs concurrently form a
+    // GM x (32/GM) patch (12 operand panels through its L2 instead of 3 + tilesN)
+    constexpr int GM = 8;
+    const int tilesM = nwg / tilesN;
+    const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
+    const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
+    const int tm = grp * GM + within % gm, tn = within / gm;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // staging: granule q = j*512 + tid -> row q>>2, physical slot q&3
+    const _Float16* a_src[2];
+    const _Float16* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = j * 512 + tid;
+        const int r = q >> 2;
+        const int sl = (q & 3) ^ swzF(r >> 2);
+        int ar = tm * BM2 + r;
+        ar = ar < M ? ar : M - 1;
+        if (a_grp > 0) ar = (ar / a_grp) * a_grp_stride + a_grp_off + (ar % a_grp);
+        a_src[j] = A + (size_t)ar * (size_t)lda + sl * 8;
+        w_src[j] = W + (size_t)(tn * BN2 + r) * (size_t)K + sl * 8;
+    }
+    auto issue_w = [&](int ks) {
+        char* base = smem + (ks & 3) * STAGE2 + HALF2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(w_src[j] + ks * BK2), (lds_ptr_t)(base + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    auto issue_a = [&](int ks) {
+        char* base = smem + (ks & 3) * STAGE2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + ks * BK2), (lds_ptr_t)(base + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+
+    const int rl = lane & 15, g = lane >> 4;
+    const int frag = rl * 64 + ((g ^ swzF(rl >> 2)) << 4);
+    const int a_off = wr * 128 * 64 + frag;                 // + half*4096 + mi*1024
+    const int b_off = HALF2 + wc * 64 * 64 + frag;          // + ni*1024
+
+    sc_f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK2;
+    // ---- prologue: steps 0..2 in flight, step 0 landed for every wave, first fragments in registers ----
+    issue_w(0); issue_a(0);
+    if (nk > 1) { issue_w(1); issue_a(1); }
+    if (nk > 2) { issue_w(2); issue_a(2); }
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // fragment sets A / B ping-pong between consecutive K-steps (no register copies)
+    sc_h8 aloA[4], ahiA[4], bcA[4], aloB[4], ahiB[4], bcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bcA[i] = *reinterpret_cast<const sc_h8*>(smem + b_off + i * 1024);
+        aloA[i] = *reinterpret_cast<const sc_h8*>(smem + a_off + i * 1024);
+        ahiA[i] = *reinterpret_cast<const sc_h8*>(smem + a_off + 4096 + i * 1024);
+    }
+    // one K-step: multiply this step's fragments (alo, ahi, bc).  After the barrier that publishes step ks+1, its 12 fragment
+    // reads and the 4 DMA issues of step ks+3 are INTERLEAVED one-per-MFMA into the second MFMA cluster
+    // (sched_group_barrier), so no wave ever sits in a load-issue burst while its SIMD's matrix pipe idles.
+    auto kstep = [&](auto sid, int ks, bool steady, sc_h8(&alo)[4], sc_h8(&ahi)[4], sc_h8(&bc)[4], sc_h8(&alo_n)[4], sc_h8(&ahi_n)[4], sc_h8(&bn)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], alo[i], acc[i][j], 0, 0, 0);
+        // step ks+1 must have landed for everyone; slot (ks-1)&3 is free after this barrier
+        if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (steady) { issue_w(ks + 3); issue_a(ks + 3); }
+        else if (ks + 3 < nk) { issue_w(ks + 3); issue_a(ks + 3); }
+        {   // unconditional (after the last step the fragments are simply unused): a branch here makes hipcc drain lgkmcnt(0)
+            const char* sn = smem + ((ks + 1) & 3) * STAGE2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bn[i] = *reinterpret_cast<const sc_h8*>(sn + b_off + i * 1024);
+                alo_n[i] = *reinterpret_cast<const sc_h8*>(sn + a_off + i * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ahi_n[i] = *reinterpret_cast<const sc_h8*>(sn + a_off + 4096 + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], ahi[i], acc[4 + i][j], 0, 0, 0);
+        if (steady) {
+            constexpr int SID = decltype(sid)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x020, 1, SID); }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, 1, SID); }
+        }
+    };
+    int ks = 0;
+    for (; ks + 4 < nk; ks += 2) {                       // steady state: both steps of the pair still issue DMA
+        kstep(std::integral_constant<int, 0>{}, ks, true, aloA, ahiA, bcA, aloB, ahiB, bcB);
+        kstep(std::integral_constant<int, 1>{}, ks + 1, true, aloB, ahiB, bcB, aloA, ahiA, bcA);
+    }
+    for (; ks + 1 < nk; ks += 2) {
+        kstep(std::integral_constant<int, 2>{}, ks, false, aloA, ahiA, bcA, aloB, ahiB, bcB);
+        kstep(std::integral_constant<int, 3>{}, ks + 1, false, aloB, ahiB, bcB, aloA, ahiA, bcA);
+    }
+    if (ks < nk) kstep(std::integral_constant<int, 4>{}, ks, false, aloA, ahiA, bcA, aloB, ahiB, bcB);
+
+    // ---- epilogue (same lane ownership as v1: 4 consecutive columns of one row) ----
+    const int m0 = tm * BM2 + wr * 128, n0 = tn * BN2 + wc * 64;
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int n = n0 + nj * 16 + g * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            sc_h4 b4 = *reinterpret_cast<const sc_h4*>(bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + mi * 16 + rl;
+            if (m < M) {
+                if (EPI == SC_EPI_SWIGLU) {
+                    const float g0 = acc[mi][nj][0] + bv[0], g1 = acc[mi][nj][1] + bv[1];
+                    const float u0 = acc[mi][nj][2] + bv[2], u1 = acc[mi][nj][3] + bv[3];
+                    const sc_h2 o = {(_Float16)(g0 / (1.0f + __expf(-g0)) * u0), (_Float16)(g1 / (1.0f + __expf(-g1)) * u1)};
+                    *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[e], EPI);
+                    if (R) {
+                        sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                    }
+                    if (OUT_F32) {
+                        *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        sc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
+    static int force = -1;                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
+    if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
+    const bool big = force == 256 || (force != 128 && M >= 1024);
+    if (big && N % BN2 == 0 && K % BK2 == 0) {
+        const int tM = (M + BM2 - 1) / BM2, tN = N / BN2;
+        const dim3 grid2((unsigned)(tM * tN)), block2(512);
+        const size_t lds2 = NSTAGE2 * STAGE2;
+        static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+        if (!attr_done[EPI * 2 + (out_f32 ? 1 : 0)]) {
+            (void)hipFuncSetAttribute(out_f32 ? (const void*)k_gemm256<EPI, true> : (const void*)k_gemm256<EPI, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr_done[EPI * 2 + (out_f32 ? 1 : 0)] = true;
+        }
+        if (out_f32)
+            hipLaunchKernelGGL((k_gemm256<EPI, true>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off);
+        else
+            hipLaunchKernelGGL((k_gemm256<EPI, false>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off);
+        SC_CHECK_LAUNCH("sc_gemm_f16");
+        return SC_OK;
+    }
     const int tilesM = (M + BM - 1) / BM, tilesN = N / BN;
     const dim3 grid((unsigned)(tilesM * tilesN)), block(256);
     const size_t lds = 2 * STAGE_BYTES;

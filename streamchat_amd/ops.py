@@ -217,7 +217,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
         raise StreamChatHipError("gemm: out/residual must be row-major")
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
-    with torch.cuda.device(a.device), _timed("k_gemm128", 2.0 * M * N * K):
+    with torch.cuda.device(a.device), _timed("k_gemm", 2.0 * M * N * K):
         check(lib.sc_gemm_f16(P(a), a.stride(0), P(w), P(bias), P(residual), 0 if residual is None else residual.stride(0), P(out),
                               out.stride(0), M, N, K, EPI[epilogue], 1 if out.dtype == torch.float32 else 0,
                               *((0, 0, 0) if a_rows is None else a_rows), stream_ptr(a.device)),
