@@ -13,6 +13,8 @@
 // rescale factors are therefore per-lane scalars: no LDS round trip and no cross-lane traffic for P; only a
 // 2-step xor-shuffle for the row max across the 4 lane groups.
 //
+// (A 3-slot ring with counted vmcnt and 8-wave blocks was measured: no gain — the kernel is VALU-bound in the softmax, PMC:
+// 8.6 VALU instructions per MFMA — so the simpler double buffer stays.)
 // Block = 4 waves x QB q-blocks of 16 queries; KV tiles of 64 rows double-buffered in LDS via 16-byte
 // global_load_lds; bank-conflict-free XOR swizzles are applied on the per-lane source address and on the reads.
 #include "sc_common.h"
@@ -26,7 +28,7 @@ typedef short sc_s4 __attribute__((ext_vector_type(4)));
 constexpr int KVT = 64;   // kv rows per tile
 
 template <int DH, int QB, bool CAUSAL>
-__global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+__global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
                                               int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,8 +41,10 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rl = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (Hq / Hkv);
-    const int qblk0 = blockIdx.x * (4 * QB * 16);
+    // 1-D grid: heads fastest, q-blocks in DESCENDING order so that under a causal mask the longest blocks are dispatched first
+    const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16);
+    const int h = blockIdx.x % Hq, b = blockIdx.x / (Hq * nqb), hk = h / (Hq / Hkv);
+    const int qblk0 = (nqb - 1 - (blockIdx.x / Hq) % nqb) * (4 * QB * 16);
     const int qw0 = qblk0 + wave * (QB * 16);
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
     const int coff = Skv - Sq;                    // causal: query i sits at kv position i + coff
@@ -154,42 +158,57 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
         }
 
         // ---- online softmax (per lane = per query column) ----
+        // m_run is kept in the scaled log2 domain; scores are scaled inside the exp2 argument with one FMA.
+        // Interior tiles (every kv visible to every query of this wave) take a mask-free path.
         sc_h8 pf[QB][2];
         const int kv_t0 = t * KVT + g * 4;
+        bool need_mask = (t * KVT + KVT > kv_valid);
+        if (CAUSAL) need_mask = need_mask || (t * KVT + KVT - 1 > qw0 + coff);      // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int qpos = qw0 + qb * 16 + rl + coff;
             float tmax = -INFINITY;
+            if (need_mask) {
+                const int qpos = qw0 + qb * 16 + rl + coff;
 #pragma unroll
-            for (int kvb = 0; kvb < 4; ++kvb)
+                for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kv = kv_t0 + kvb * 16 + r;
-                    float x = s[kvb][qb][r] * scale_log2;
-                    const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
-                    x = dead ? -INFINITY : x;
-                    s[kvb][qb][r] = x;
-                    tmax = fmaxf(tmax, x);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int kv = kv_t0 + kvb * 16 + r;
+                        const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                        const float x = dead ? -INFINITY : s[kvb][qb][r];
+                        s[kvb][qb][r] = x;
+                        tmax = fmaxf(tmax, x);
+                    }
+            } else {
+#pragma unroll
+                for (int kvb = 0; kvb < 4; ++kvb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qb], tmax);
+            const float m_new = fmaxf(m_run[qb], tmax * scale_log2);                 // scale > 0: max commutes with scaling
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
-            m_run[qb] = m_new;
             float psum = 0.f;
 #pragma unroll
             for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[kvb][qb][r] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, -m_use));
                     psum += p;
                     pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p;
                 }
-            l_run[qb] = l_run[qb] * alpha + psum;
+            // exact skip: if no query of this wave raised its running max, alpha == 1 for every lane
+            if (__any(m_new != m_run[qb])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+                l_run[qb] = l_run[qb] * alpha + psum;
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                o[db][qb][0] *= alpha; o[db][qb][1] *= alpha; o[db][qb][2] *= alpha; o[db][qb][3] *= alpha;
+                for (int db = 0; db < DB; ++db) {
+                    o[db][qb][0] *= alpha; o[db][qb][1] *= alpha; o[db][qb][2] *= alpha; o[db][qb][3] *= alpha;
+                }
+                m_run[qb] = m_new;
+            } else {
+                l_run[qb] += psum;
             }
         }
 
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(256) void k_attn(const _Float16* __restrict__ Q, in
 template <int DH, int QB>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
                 int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, hipStream_t s) {
-    const dim3 grid((unsigned)((Sq + 4 * QB * 16 - 1) / (4 * QB * 16)), (unsigned)Hq, (unsigned)B), block(256);
+    const dim3 grid((unsigned)(((Sq + 4 * QB * 16 - 1) / (4 * QB * 16)) * Hq * B)), block(256);
     const size_t lds = 2 * 2 * KVT * DH * 2;
     const float sl2 = scale * 1.4426950408889634f;
     if (causal)
@@ -259,7 +278,6 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sc_attention_f16: leading dims must be multiples of 8 (out: 4)");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(out) & 7) == 0, "sc_attention_f16: q/k/v must be 16-byte aligned, out 8-byte");
-    SC_REQUIRE(B <= 65535 && Hq <= 65535, "sc_attention_f16: B and Hq must be <= 65535");
     hipStream_t s = (hipStream_t)stream;
     if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
     if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);

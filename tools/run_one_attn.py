@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from streamchat_amd import ops
+S = int(sys.argv[1]); Hq, Hkv, Dh, causal = 28, 4, 128, True
+if len(sys.argv) > 2 and sys.argv[2] == "vit":
+    B, S, Hq, Hkv, Dh, causal = 56, 577, 16, 16, 64, False
+else:
+    B = 1
+q = torch.randn(B, S, Hq * Dh, device="cuda").half(); k = torch.randn(B, S, Hkv * Dh, device="cuda").half(); v = torch.randn(B, S, Hkv * Dh, device="cuda").half()
+out = torch.empty(B, S, Hq * Dh, device="cuda", dtype=torch.float16)
+for _ in range(3):
+    ops.attention(q, k, v, Hq, Hkv, Dh, Dh ** -0.5, causal, out=out)
+torch.cuda.synchronize()
