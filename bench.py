@@ -21,7 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from streamchat_amd import llm as LM, ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
+from streamchat_amd import dist as DD, llm as LM, ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
 from streamchat_amd.memory_bank.memory_retrieval import local_doc_qa as Q   # noqa: E402
 
 FRAMES = 1024
@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-llm", action="store_true", help="C2 workload: stop after retrieval (no 7B prefill)")
     ap.add_argument("--decode-tokens", type=int, default=8, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
     return ap.parse_args()
 
 
@@ -106,6 +107,55 @@ class Pipeline:
             self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
         return self.last
 
+    def step_sharded(self, ctx):
+        """N > 1: the stream of world*frames frames is dealt to the ranks by whole chunks.  Encode, chunk captions and the chunk-group
+        k-means are rank-local; rank 0 searches the all-gathered node METADATA; only the selected frames (short memory + retrieved
+        chunks) cross xGMI in one fixed-capacity all_gather; rank 0 prefills the 7B model."""
+        parts = DD.partition_chunks(self.n * ctx.world, MEM["chunk_size"], ctx.world)
+        a, b = parts[ctx.rank]
+        self.enc.encode_frames_u8(self.frames[: b - a], out=self.feats[: b - a])
+        bank = [self.feats[i:i + 1] for i in range(b - a)]
+        cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
+        cap.n = a // MEM["chunk_size"]                                     # global chunk numbering of the synthetic captions
+        torch.manual_seed(0)
+        tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
+        # ---- metadata to rank 0: per top-level node (depth, text, children (text, frame range)), + short-memory frame ids ----
+        base = self.feats.data_ptr()
+        fsz = self.feats[0].numel() * self.feats.element_size()
+        gidx = lambda t: a + (t.data_ptr() - base) // fsz                     # global index of a bank view's first frame
+        def desc(n):
+            rng = (int(gidx(n.centroids)), int(gidx(n.centroids)) + n.centroids.shape[0]) if n.depth == 0 else None
+            return dict(depth=n.depth, text=n.text, frames=rng, children=[desc(c) for c in n.children])
+        meta = DD.gather_objects(ctx, dict(nodes=[desc(n) for n in tree], short=[int(gidx(t)) for t in short]))
+        wanted = None
+        if ctx.is_root:
+            def proxy(d):
+                n = U.MultimodalTreeNode(d["frames"], d["text"], depth=d["depth"])
+                n.children = [proxy(c) for c in d["children"]]
+                return n
+            nodes = [proxy(d) for m in meta for d in m["nodes"]]
+            lm = Q.LocalMemoryRetrieval()
+            lm.init_cfg("minilm-l6", top_k=1, language="en", embedder=self.sent)
+            lm.search_memory(self.question, Q.FlatL2VectorStore(self.docs, lm._embed_docs(self.docs), self.sent.embed_query))
+            path, path_text = U.fast_search_tree_multi_modal_with_embedding(nodes, self.question, self.feats[0], self.colbert, self.tok,
+                                                                            cache=U.CaptionEmbeddingCache())
+            wanted = list(meta[-1]["short"]) + [f for rng in path for f in range(rng[0], rng[1])]
+            self.last = dict(path_text=path_text)
+        wanted = DD.broadcast_object(ctx, wanted)
+        sel = DD.gather_selected_frames(ctx, self.feats[: b - a], (a, b), wanted, capacity=2 * MEM["chunk_size"] + MEM["remember_window"])
+        if ctx.is_root and self.model is not None:
+            image_embeddings = sel.reshape(-1, sel.shape[-1])
+            qs = S.build_answer_prompt(self.question, self.last["path_text"][-1], None)
+            conv = S.conv_templates["qwen_1_5"].copy()
+            conv.append_message(conv.roles[0], qs)
+            conv.append_message(conv.roles[1], None)
+            from streamchat_amd.mm_utils import tokenizer_image_token
+            ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
+            out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
+                                                           max_new_tokens=1)
+            self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
+        return self.last if ctx.is_root else None
+
     def decode_rate(self, n_tokens):
         """greedy decode tokens/s on the context left in the KV cache by the last step (reported separately from the metric)"""
         lm = self.model.lm
@@ -161,7 +211,16 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    pipe = Pipeline(dev, a.frames, seed=1234 + rank, with_llm=not a.no_llm)
+    ctx = DD.DistContext(rank, world, dev, "nccl")
+    # weak scaling: world * frames frames in total; the 7B model lives on rank 0 only (single-GPU LLM stage)
+    pipe = Pipeline(dev, a.frames + MEM["chunk_size"], seed=1234 + rank, with_llm=(not a.no_llm) and rank == 0) if world > 1 else \
+        Pipeline(dev, a.frames, seed=1234 + rank, with_llm=not a.no_llm)
+    if world > 1:
+        pipe.n = a.frames
+    if a.force_sharded and world == 1:
+        pipe = Pipeline(dev, a.frames + MEM["chunk_size"], seed=1234, with_llm=not a.no_llm)
+        pipe.n = a.frames
+    run_step = (lambda: pipe.step_sharded(ctx)) if (world > 1 or a.force_sharded) else pipe.step
 
     def barrier():
         if world > 1:
@@ -170,12 +229,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        pipe.step()
+        run_step()
     barrier()
     t0 = time.perf_counter()
     with ops.KernelTimer() as kt:
         for _ in range(a.steps):
-            pipe.step()
+            run_step()
         barrier()
         dt = time.perf_counter() - t0
         prof = kt.summary()
@@ -207,7 +266,7 @@ def main():
                            context_tokens=pipe.last.get("context"),
                            frames_per_gpu=a.frames, micro_batch=56, parallelism=f"dp{world}", weights="random-init"),
                roofline=roof, stages=stages)
-    if full and a.decode_tokens > 0:
+    if full and a.decode_tokens > 0 and world == 1:
         out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames)
