@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Streaming video-QA entry point — MI355X-native drop-in for the reference's `inference_streaming_longva_v2.py`.
+
+Same command line (reference :48-87) and the same per-video / per-question control flow (`run_inference`, reference :680-933):
+  read + encode the segment -> update short/long memory -> retrieve dialogue + visual memory -> answer -> persist.
+The functions it drives keep the reference's names (streamchat_amd.streaming / utiles / memory_bank / llm); everything under
+them runs on hand-written gfx950 kernels.  Differences: ONE model replica serves both answering and chunk captioning (the
+reference loads two 7B copies on cuda:0 / cuda:1, :697-700); generation uses a KV cache.
+
+Offline operation: `--synthetic N` runs N synthetic videos (seeded scene-structured frames, random-init weights of the real
+architectures, hash tokenizers) — there are no checkpoints or datasets in this environment.  With real checkpoints pass
+`--model_name` (LongVA-7B state dict directory) and `--embedding_model_id`; see INTEGRATION.md §A."""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from streamchat_amd import llm as LM, streaming as S, synthetic, text as T, utiles as U, vision as V
+from streamchat_amd.memory_bank.memory_retrieval.local_doc_qa import HipSentenceEmbeddings, LocalMemoryRetrieval
+from streamchat_amd.memory_bank.memory_utils import enter_name, save_local_memory
+from streamchat_amd.memory_bank.prompt_utils import only_related_prompt_dict_ego
+
+
+def parse_args(argv=None):
+    """Command-line arguments of the reference (:48-87) + `--synthetic` / `--embedding_model_id` / `--tiny`."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--video_dir", help="Directory containing video files.", required=True)
+    p.add_argument("--model_name", type=str, required=True)
+    p.add_argument("--conv-mode", type=str, required=False, default="video-chatgpt_v1")
+    p.add_argument("--mode", type=str, required=False, default="off_line")
+    p.add_argument("--chunk_size", type=int, default=20)
+    p.add_argument("--num_clusters", type=int, default=5)
+    p.add_argument("--interval", type=int, default=10)
+    p.add_argument("--short_window", type=int, default=20)
+    p.add_argument("--remember_window", type=int, default=5)
+    p.add_argument("--tau", type=int, default=5)
+    p.add_argument("--compress_rate", type=int, default=1)
+    p.add_argument("--num_chunks", type=int, default=1)
+    p.add_argument("--chunk_idx", type=int, default=0)
+    p.add_argument("--num_frames", type=int, default=4)
+    p.add_argument("--device", type=str, required=False, default="cuda:0")
+    p.add_argument("--model-base", type=str, default=None)
+    p.add_argument("--num_beams", type=int, default=1)
+    p.add_argument("--temperature", type=float, default=0.2)
+    p.add_argument("--sample_rate", type=float, default=0.5)
+    p.add_argument("--top_p", type=float, default=None)
+    p.add_argument("--memory_basic_dir", type=str, required=True, default="/Ours/memory_bank/memories")
+    p.add_argument("--memory_file", type=str, required=False, default="updata_memories_for_streaming.json")
+    p.add_argument("--save_file", type=str, required=True, default="result_for_streaming.json")
+    p.add_argument("--annotations", type=str, required=True, default="result_for_streaming.json")
+    p.add_argument("--language", type=str, required=True, default="en")
+    p.add_argument("--memory_search_top_k", type=int, default=1)
+    p.add_argument("--ppl", action="store_true", help="weather to calculate ppl")
+    p.add_argument("--multi_modal_memory", action="store_true", help="weather to open multi-modal memory")
+    # additions
+    p.add_argument("--synthetic", type=int, default=0, help="run N synthetic videos instead of --annotations / --video_dir")
+    p.add_argument("--embedding_model_id", type=str, default=None, help="mxbai-colbert-large-v1 checkpoint (reference :703)")
+    p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
+    p.add_argument("--max_new_tokens", type=int, default=256)
+    return p.parse_args(argv)
+
+
+class SyntheticCapture:
+    """cv2.VideoCapture stand-in: `read_rgb(frame_number)` over a seeded scene-structured stream."""
+    def __init__(self, n_frames, fps=2, size=336, seed=0, device="cpu"):
+        self.frames = torch.from_numpy(synthetic.frame_stream(n_frames, seed=seed, h=size, w=size)).to(device)
+        self.n, self.fps = n_frames, fps
+
+    def read_rgb(self, i):
+        return self.frames[i] if 0 <= i < self.n else None
+
+
+class Cv2Capture:
+    def __init__(self, path):
+        import cv2                                           # host decode stays on the CPU (out of the GPU hot path)
+        self.cv2, self.cap = cv2, cv2.VideoCapture(path)
+        self.n = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        self.fps = int(self.cap.get(cv2.CAP_PROP_FPS))
+
+    def read_rgb(self, i):
+        self.cap.set(self.cv2.CAP_PROP_POS_FRAMES, i)
+        ret, frame = self.cap.read()
+        return self.cv2.cvtColor(frame, self.cv2.COLOR_BGR2RGB) if ret else None
+
+
+def build_models(args):
+    """Random-init models of the real (or --tiny) architectures.  Loading real checkpoints: INTEGRATION.md §A."""
+    dev = args.device
+    if args.tiny:
+        vc = V.CLIPVisionConfigLite(hidden=128, layers=3, heads=2, intermediate=256, patch=14, image_size=56)
+        qc = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=32768)
+        bc = T.BertConfigLite(hidden=128, layers=2, heads=2, intermediate=256)
+        mc = T.BertConfigLite(hidden=128, layers=2, heads=4, intermediate=256)
+    else:
+        vc, qc = V.CLIPVisionConfigLite(**V.VIT_L_336), LM.Qwen2ConfigLite(**LM.QWEN2_7B)
+        bc, mc = T.BertConfigLite(**T.BERT_LARGE), T.BertConfigLite(**T.MINILM_L6)
+    enc = V.FrameEncoder(V.CLIPVisionTower(V.random_clip_state_dict(vc, device=dev), vc, device=dev),
+                         V.MMProjector(V.random_projector_state_dict(vc.hidden, qc.hidden, device=dev), device=dev))
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(LM.random_qwen2_state_dict(qc, device=dev), qc, device=dev, max_seq=65536, consume=True), enc)
+    embedding_model = T.BertEncoder(T.random_bert_state_dict(bc, seed=2, device=dev), bc, device=dev)
+    sentence = HipSentenceEmbeddings(T.SentenceEmbedder(T.BertEncoder(T.random_bert_state_dict(mc, seed=3, device=dev), mc, device=dev)), T.HashTokenizer())
+    return model, synthetic.SyntheticTokenizer(), embedding_model, T.HashTokenizer(), sentence, vc
+
+
+def inference_thread_with_memory_and_dialogue_retrival_test(long_memory_tree_cache, short_memory_buffer_cache, fps, model, embedding_model, tokenizer,
+                                                            embedding_tokenizer, time_line, num_frames, conv_mode, chat, memory_config, args,
+                                                            save_file, question, labels, qa_class, time, output_loss=False):
+    """reference :588-677: dialogue-memory prompt -> multi-modal answer -> append to the results JSON."""
+    with open(save_file, "r", encoding="utf-8") as f:
+        existing_data = json.load(f)
+    with torch.no_grad():
+        searched_history = U.build_prompt_with_search_memory_only_related(
+            question, memory_config["user_name"], memory_config["user_memory_index"], memory_config["local_memory_qa"],
+            memory_config["only_related_prompt"], memory_config["user_keyword"], memory_config["ai_keyword"], memory_config["boot_actual_name"])
+        output, process_time, generate_time = S.longva_inference_with_embedding_multi_modal(
+            question, num_frames, conv_mode, model, embedding_model, tokenizer, embedding_tokenizer, chat, short_memory_buffer_cache,
+            long_memory_tree_cache, searched_history, temperature=args.temperature, top_p=args.top_p, num_beams=args.num_beams,
+            max_new_tokens=args.max_new_tokens)
+    existing_data.append({"time": time, "question": question, "label": labels, "predict": output, "class": qa_class, "process_time": process_time})
+    with open(save_file, "w", encoding="utf-8") as f:
+        json.dump(existing_data, f, ensure_ascii=False, indent=4)
+    return output
+
+
+def run_inference(args):
+    """reference :680-933"""
+    main_device = args.device
+    model, tokenizer, embedding_model, embedding_tokenizer, sentence, vc = build_models(args)
+    conv_mode = args.conv_mode if args.conv_mode in S.conv_templates else "qwen_1_5"
+    if args.synthetic:
+        all_annotations = [{"info": {"video_path": f"synthetic_{i}", "class_1": "synthetic"},
+                            "breakpoint": [{"time": 60 * (j + 1), "question": f"what happened around {synthetic.caption(j, words=3)}?", "answer": "n/a",
+                                            "class": "synthetic"} for j in range(2)]} for i in range(args.synthetic)]
+    else:
+        all_annotations = json.load(open(args.annotations, "r"))
+    inference_count = 0
+    for anno in all_annotations:
+        os.makedirs(args.memory_basic_dir, exist_ok=True)
+        args.memory_file = "memory_{}.json".format(inference_count)
+        memory_dir = os.path.join(args.memory_basic_dir, args.memory_file)
+        save_file = args.save_file
+        if not os.path.exists(memory_dir):
+            json.dump({}, open(memory_dir, "w", encoding="utf-8"))
+        if not os.path.exists(save_file):
+            json.dump([], open(save_file, "w", encoding="utf-8"))
+        language = args.language
+        local_memory_qa = LocalMemoryRetrieval()
+        local_memory_qa.init_cfg(embedding_model="minilm-l6", embedding_device=main_device, top_k=args.memory_search_top_k, language=language,
+                                 embedder=sentence)
+        only_related_prompt = only_related_prompt_dict_ego()[language]
+        memory = json.loads(open(memory_dir, "r", encoding="utf-8").read())
+        user_name = "User"
+        hello_msg, user_memory, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)
+        memory_config = dict(user_memory=user_memory, user_name=user_name, user_memory_index=user_memory_index, local_memory_qa=local_memory_qa,
+                             only_related_prompt=only_related_prompt, user_keyword="[|User|]", ai_keyword="[|AI|]", boot_actual_name="AI",
+                             language=language, memory=memory)
+        question_list = anno["breakpoint"]
+        time_line = [int(q["time"]) for q in question_list]
+        if args.synthetic:
+            cap = SyntheticCapture(int(time_line[-1] * 2), fps=2, size=vc.image_size, seed=inference_count, device=main_device)
+        else:
+            video_path = os.path.join(args.video_dir, anno["info"]["class_1"], anno["info"]["video_path"])
+            assert os.path.exists(video_path), "{} not exist ".format(video_path)
+            cap = Cv2Capture(video_path)
+        total_frames, frame_rate = cap.n, cap.fps
+        frame_line = [0] + time_line
+        long_memory_tree, short_memory_buffer = None, None
+        for questions, star, end in zip(question_list, frame_line[:-1], frame_line[1:]):
+            question, labels, qa_class = questions["question"], questions["answer"], questions["class"]
+            feature_bank = S.video_reader_thread_with_embedding(cap, total_frames, frame_rate, None, model, star, end, main_device, args.sample_rate,
+                                                                chunk_size=args.chunk_size)
+            if len(feature_bank) > 0:
+                long_memory_tree, short_memory_buffer = S.updating_memory_buffer(
+                    feature_bank, long_memory_tree, model, tokenizer, args.multi_modal_memory, short_window=args.short_window,
+                    remember_window=args.remember_window, tau=args.tau, compress_rate=args.compress_rate, chunk_size=args.chunk_size,
+                    num_clusters=args.num_clusters, interval=args.interval)
+            output = inference_thread_with_memory_and_dialogue_retrival_test(
+                long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
+                args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"])
+            # persist the dialogue turn and refresh the retrieval index (reference :918-920)
+            memory = save_local_memory(memory, [[question, output]], user_name, args)
+            _, _, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)
+            memory_config["user_memory_index"] = user_memory_index
+        inference_count += 1
+
+
+if __name__ == "__main__":
+    run_inference(parse_args())

@@ -204,8 +204,7 @@ class LlavaQwenForCausalLM:
                                       top_p=None, num_beams=1, max_new_tokens=256, use_cache=True, generator=None, **kwargs):
         """llava_qwen.py:137-155 -> Qwen2 generate(inputs_embeds=...).  Returns the NEW token ids [1, n] like HF does for
         inputs_embeds prompts.  `use_cache` is accepted for call compatibility; a KV cache is always used."""
-        if image_embeddings is not None or True:
-            _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
+        _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
         new = []

@@ -140,7 +140,7 @@ def longva_inference_with_embedding_multi_modal(question, num_frames, conv_mode,
     conv.append_message(conv.roles[1], None)
     input_ids = tokenizer_image_token(conv.get_prompt(), tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0)
     time_1 = time.time()
-    with torch.inference_mode():
+    with torch.no_grad():        # (not inference_mode: the persistent activation buffers are reused outside)
         output_ids = model.generate_with_image_embedding(input_ids, image_embeddings=[image_embeddings], modalities=["video"],
                                                          do_sample=True if temperature > 0 else False, temperature=temperature, top_p=top_p,
                                                          num_beams=num_beams, max_new_tokens=max_new_tokens, use_cache=False)

@@ -1,0 +1,31 @@
+"""GPU: the streaming entry point end to end (tiny random-init architectures, synthetic video): encode -> memory update (with
+k-means merges) -> dialogue + tree retrieval -> generate -> persisted results and dialogue memory."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_inference_synthetic_tiny(tmp_path):
+    import inference_streaming_longva_v2 as E
+    args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(tmp_path / "mem"), "--save_file",
+                         str(tmp_path / "out.json"), "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "1",
+                         "--tiny", "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3",
+                         "--max_new_tokens", "4", "--multi_modal_memory"])
+    E.run_inference(args)
+    out = json.load(open(tmp_path / "out.json"))
+    assert len(out) == 2 and all(set(r) == {"time", "question", "label", "predict", "class", "process_time"} for r in out)
+    mem = json.load(open(tmp_path / "mem" / "memory_0.json"))
+    turns = [t for day in mem["User"]["history"].values() for t in day]
+    assert [t["query"] for t in turns] == [r["question"] for r in out]
+    assert os.path.exists(tmp_path / "mem" / "memory_index" / "User_index" / "index.npy")      # dialogue index rebuilt per round
+
+
+def test_parse_args_has_reference_flags():
+    import inference_streaming_longva_v2 as E
+    a = E.parse_args(["--video_dir", "v", "--model_name", "m", "--memory_basic_dir", "d", "--save_file", "s", "--annotations", "a", "--language", "en"])
+    for k, v in dict(chunk_size=20, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5, compress_rate=1, sample_rate=0.5,
+                     temperature=0.2, num_beams=1, memory_search_top_k=1, conv_mode="video-chatgpt_v1", mode="off_line").items():
+        assert getattr(a, k) == v
