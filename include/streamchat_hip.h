@@ -125,6 +125,10 @@ int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const v
  * patch [N*P, D], cls [D], pos [P+1, D], out [N*(P+1), D], all fp16; D % 8 == 0, D <= 4096. */
 int sc_vit_embed_ln_f16(const void* patch, const void* cls, const void* pos, const void* gamma,
                         const void* beta, float eps, void* out, int N, int P, int D, sc_stream_t stream);
+/* Decode-time matrix-vector product y[N] = W[N,K] . x[K] (+ bias) (+ residual): weights streamed once (HBM-bound).
+ * epilogue SC_EPI_NONE or SC_EPI_SWIGLU (interleaved gate/up rows, y has N/2 entries).  K % 8 == 0. */
+int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K,
+                int epilogue, int out_f32, sc_stream_t stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim, fp32 statistics; [rows, cols] fp16, cols % 8 == 0,
  * cols <= 4096. */
 int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y,
@@ -156,10 +160,12 @@ int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L
  *   k,v [B, Skv, Hkv, Dh]  row strides ldk / ldv (GQA: Hq % Hkv == 0)
  *   out [B, Sq,  Hq,  Dh]  row stride ldo
  *   causal: 0 = full; 1 = causal with the Sq queries aligned to the END of the Skv keys
- *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {32, 64, 128}. */
+ *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {32, 64, 128}.
+ *   nsplit > 1: split-KV ("flash-decoding") for few queries over a long cache — the key range is cut into nsplit slices
+ *   processed by separate workgroups and merged; needs ws of B*Hq*Sq*nsplit*(Dh+2)*4 bytes.  nsplit = 1: ws may be NULL. */
 int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                      int ldo, int B, int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal,
-                     const int32_t* kv_len, sc_stream_t stream);
+                     const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, sc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,8 @@ constexpr int KVT = 64;   // kv rows per tile
 template <int DH, int QB, bool CAUSAL>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
-                                              int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len) {
+                                              int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
+                                              float* __restrict__ part, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KVT * DH * 2;            // bytes per K (or V) tile
     constexpr int STAGE = 2 * TILE;
@@ -43,8 +44,9 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     const int rl = lane & 15, g = lane >> 4;
     // 1-D grid: heads fastest, q-blocks in DESCENDING order so that under a causal mask the longest blocks are dispatched first
     const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16);
-    const int h = blockIdx.x % Hq, b = blockIdx.x / (Hq * nqb), hk = h / (Hq / Hkv);
-    const int qblk0 = (nqb - 1 - (blockIdx.x / Hq) % nqb) * (4 * QB * 16);
+    const int split = blockIdx.x % nsplit, bid = blockIdx.x / nsplit;            // split-KV (flash-decoding) index fastest
+    const int h = bid % Hq, b = bid / (Hq * nqb), hk = h / (Hq / Hkv);
+    const int qblk0 = (nqb - 1 - (bid / Hq) % nqb) * (4 * QB * 16);
     const int qw0 = qblk0 + wave * (QB * 16);
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
     const int coff = Skv - Sq;                    // causal: query i sits at kv position i + coff
@@ -135,11 +137,15 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
 
-    if (nt > 0) stage(0, 0);
+    // split-KV: this block covers tiles [t_lo, t_hi)
+    const int per = (nt + nsplit - 1) / nsplit;
+    const int t_lo = split * per;
+    const int t_hi = (t_lo + per) < nt ? (t_lo + per) : nt;
+    if (t_lo < t_hi) stage(0, t_lo);
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
         const char* sk = smem + cur * STAGE;
         const char* sv = sk + TILE;
 
@@ -238,7 +244,14 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         l += __shfl_xor(l, 32, 64);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qr = qw0 + qb * 16 + rl;
-        if (qr < Sq) {
+        if (part) {            // split-KV partial: unnormalised O (fp32), running max (scaled log2 domain) and sum
+            if (qr < Sq) {
+                float* pp = part + ((((size_t)b * Hq + h) * Sq + qr) * nsplit + split) * (DH + 2);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) *reinterpret_cast<sc_f4*>(pp + db * 16 + g * 4) = o[db][qb];
+                if (g == 0) { pp[DH] = m_run[qb]; pp[DH + 1] = l; }
+            }
+        } else if (qr < Sq) {
             _Float16* op = O + ((size_t)b * Sq + qr) * (size_t)ldo + h * DH + g * 4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -250,18 +263,38 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     }
 }
 
+// merge of the split-KV partials: out = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
+template <int DH>
+__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit) {
+    const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
+    const int q = row % Sq, bh = row / Sq, h = bh % Hq, b = bh / Hq;
+    const int d = threadIdx.x;
+    const float* pp = part + (size_t)row * nsplit * (DH + 2);
+    float M = -INFINITY;
+    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, pp[i * (DH + 2) + DH]);
+    float num = 0.f, den = 0.f;
+    for (int i = 0; i < nsplit; ++i) {
+        const float m = pp[i * (DH + 2) + DH];
+        const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+        num += pp[i * (DH + 2) + d] * w;
+        den += pp[i * (DH + 2) + DH + 1] * w;
+    }
+    O[((size_t)b * Sq + q) * (size_t)ldo + h * DH + d] = (_Float16)(den > 0.f ? num / den : 0.f);
+}
+
 template <int DH, int QB>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
-                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, hipStream_t s) {
-    const dim3 grid((unsigned)(((Sq + 4 * QB * 16 - 1) / (4 * QB * 16)) * Hq * B)), block(256);
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, hipStream_t s) {
+    const dim3 grid((unsigned)(((Sq + 4 * QB * 16 - 1) / (4 * QB * 16)) * Hq * B * nsplit)), block(256);
     const size_t lds = 2 * 2 * KVT * DH * 2;
     const float sl2 = scale * 1.4426950408889634f;
     if (causal)
         hipLaunchKernelGGL((k_attn<DH, QB, true>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit);
     else
         hipLaunchKernelGGL((k_attn<DH, QB, false>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit);
+    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit);
     SC_CHECK_LAUNCH("sc_attention_f16");
     return SC_OK;
 }
@@ -270,7 +303,7 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
 
 extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
                                 int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
-                                sc_stream_t stream) {
+                                int nsplit, void* ws, size_t ws_bytes, sc_stream_t stream) {
     SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
     SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
     SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
@@ -279,7 +312,14 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(out) & 7) == 0, "sc_attention_f16: q/k/v must be 16-byte aligned, out 8-byte");
     hipStream_t s = (hipStream_t)stream;
-    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
-    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
-    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, s);
+    SC_REQUIRE(nsplit >= 1 && nsplit <= 1024, "sc_attention_f16: nsplit must be in [1, 1024]");
+    float* part = nullptr;
+    if (nsplit > 1) {
+        const size_t need = (size_t)B * Hq * Sq * nsplit * (Dh + 2) * sizeof(float);
+        if (!ws || ws_bytes < need) return sc_fail(SC_ERR_WORKSPACE, "sc_attention_f16: split-KV workspace %zu < required %zu", ws_bytes, need);
+        part = (float*)ws;
+    }
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
 }

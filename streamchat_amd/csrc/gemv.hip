@@ -1,0 +1,81 @@
+// Decode-time projections: y[N] = W[N,K] . x[K] (+ bias) (+ residual), fp16 weights streamed ONCE from HBM (batch-1 decode
+// is a pure weight stream: 14.1 GB per token for Qwen2-7B — SURVEY.md §8(d)); replaces the M = 1 calls of
+// transformers' nn.Linear inside Qwen2ForCausalLM.generate (reference llava_qwen.py:155).
+// One wave owns RPW = 4 output rows: per K-slice of 512 it loads 16 bytes of x per lane once (L1/L2 resident) and 16 bytes of
+// each of its 4 weight rows (1 KiB coalesced per row), accumulates with v_dot2_f32_f16, and finishes with a wave reduction.
+// No LDS: the operand is streamed once per block and never shared (cdna guide §5 "GEMV / M <= 16" row).
+#include "sc_common.h"
+
+namespace {
+
+constexpr int RPW = 4;     // rows per wave
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
+                                              const _Float16* __restrict__ res, void* __restrict__ y, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= N) return;
+    float acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+    const _Float16* wp[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
+    for (int k = lane * 8; k < K; k += 512) {
+        const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+        sc_h8 wv[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp[r] + (k - lane * 8)));
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const sc_h2 a = {wv[r][e], wv[r][e + 1]}, b = {xv[e], xv[e + 1]};
+                acc[r] = __builtin_amdgcn_fdot2(a, b, acc[r], false);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
+    }
+    if (lane == 0) {
+        if (SWIGLU) {          // rows (g g u u): two outputs per 4 rows
+            const float g0 = acc[0], g1 = acc[1], u0 = acc[2], u1 = acc[3];
+            _Float16* o = reinterpret_cast<_Float16*>(y) + (row0 >> 1);
+            o[0] = (_Float16)(g0 / (1.0f + __expf(-g0)) * u0);
+            o[1] = (_Float16)(g1 / (1.0f + __expf(-g1)) * u1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int n = row0 + r;
+                if (n < N) {
+                    float v = acc[r] + (bias ? (float)bias[n] : 0.f) + (res ? (float)res[n] : 0.f);
+                    if (OUT_F32) reinterpret_cast<float*>(y)[n] = v;
+                    else reinterpret_cast<_Float16*>(y)[n] = (_Float16)v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K, int epilogue,
+                           int out_f32, sc_stream_t stream) {
+    SC_REQUIRE(W && x && y, "sc_gemv_f16: null pointer argument");
+    SC_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "sc_gemv_f16: K must be a positive multiple of 8");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "sc_gemv_f16: W and x must be 16-byte aligned");
+    SC_REQUIRE(epilogue == SC_EPI_NONE || epilogue == SC_EPI_SWIGLU, "sc_gemv_f16: epilogue must be NONE or SWIGLU");
+    SC_REQUIRE(epilogue != SC_EPI_SWIGLU || (N % 4 == 0 && !bias && !residual && !out_f32), "sc_gemv_f16: SwiGLU needs N % 4 == 0, no bias/residual, fp16 out");
+    const dim3 grid((unsigned)((N + 4 * RPW - 1) / (4 * RPW))), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16 *w = (const _Float16*)W, *xx = (const _Float16*)x, *b = (const _Float16*)bias, *r = (const _Float16*)residual;
+    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false>), grid, block, 0, s, w, xx, b, r, y, N, K);
+    else if (out_f32) hipLaunchKernelGGL((k_gemv<false, true>), grid, block, 0, s, w, xx, b, r, y, N, K);
+    else hipLaunchKernelGGL((k_gemv<false, false>), grid, block, 0, s, w, xx, b, r, y, N, K);
+    SC_CHECK_LAUNCH("sc_gemv_f16");
+    return SC_OK;
+}

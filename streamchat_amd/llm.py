@@ -108,6 +108,8 @@ class Qwen2Model:
         n, pos0 = embeds.shape[0], self.cache_len
         if pos0 + n > self.max_seq:
             raise ValueError(f"sequence {pos0 + n} exceeds the KV cache ({self.max_seq})")
+        if n == 1:
+            return self._decode_one(embeds)
         B = self._buffers(n)
         dq, dkv, Dh = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim
         h = B["h"][:n]
@@ -161,6 +163,38 @@ def splice_image_embeddings(ids, embed_table, image_features, max_len=None, labe
     if max_len is not None:
         out, labels_out = out[:max_len], labels_out[:max_len]
     return out, labels_out
+
+
+def _decode_one(self, embeds):
+    """One decode step (batch 1): every projection is a GEMV that streams its weights once (HBM-bound), attention is split-KV
+    over the cache with the G = Hq/Hkv query heads of a KV group packed as G query rows (so each K/V byte is read once)."""
+    c = self.cfg
+    pos0, S = self.cache_len, self.cache_len + 1
+    dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
+    h = embeds.reshape(1, -1)
+    nsplit = max(1, min(128, ((S + 63) // 64) // 2))
+    for l, L in enumerate(self.L):
+        x = ops.rmsnorm(h, L["ln1"], c.eps)
+        q = ops.gemv(L["wq"], x, L["bq"]).view(1, dq)
+        kv = self.cache[l][pos0:S]
+        ops.gemv(L["wkv"], x, L["bkv"], out=kv)
+        ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
+        ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
+        ck = self.cache[l][:S]
+        qp = q.view(c.kv_heads, G, Dh).transpose(0, 1).reshape(1, G, dkv).contiguous()          # heads of a KV group -> query rows
+        op = ops.attention(qp, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,
+                           causal=False, nsplit=nsplit)
+        att = op.view(G, c.kv_heads, Dh).transpose(0, 1).reshape(1, dq).contiguous()
+        h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
+        x = ops.rmsnorm(h2, L["ln2"], c.eps)
+        m = ops.gemv(L["wgu"], x, None, epilogue="swiglu")
+        h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
+    self.cache_len = S
+    xn = ops.rmsnorm(h, self.norm, c.eps)
+    return ops.gemv(self.lm_head, xn, None, out_f32=True)
+
+
+Qwen2Model._decode_one = _decode_one
 
 
 class LlavaQwenForCausalLM:

@@ -251,7 +251,7 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
     return out
 
 
-def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None):
+def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1):
     """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused
     QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh]."""
     _require_cuda(q, k, v)
@@ -266,9 +266,11 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
     kl = None if kv_len is None else kv_len.to(device=q.device, dtype=torch.int32).contiguous()
+    ws = _workspace(B * Hq * Sq * nsplit * (Dh + 2) * 4, q.device) if nsplit > 1 else None
     with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), out.stride(1), B, Sq, Skv, Hq, Hkv, Dh,
-                                   c_float(scale), 1 if causal else 0, P(kl), stream_ptr(q.device)), "sc_attention_f16")
+                                   c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel()),
+                                   stream_ptr(q.device)), "sc_attention_f16")
     return out
 
 
@@ -355,3 +357,18 @@ def rope_(x, heads: int, Dh: int, theta: float, pos0: int = 0, positions=None):
         check(lib.sc_rope_f16(c_void_p(x.data_ptr()), x.stride(0), ptr(pos), pos0, x.shape[0], heads, Dh, c_float(theta),
                               stream_ptr(x.device)), "sc_rope_f16")
     return x
+
+
+def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False):
+    """y[N] = w[N,K] @ x[K] (+ bias) (+ residual): batch-1 decode projection (weights streamed once)."""
+    _require_cuda(w, x)
+    lib = _lib.load()
+    N, K = w.shape
+    x = x.reshape(-1)
+    n_out = N // 2 if epilogue == "swiglu" else N
+    if out is None:
+        out = torch.empty(n_out, dtype=torch.float32 if out_f32 else torch.float16, device=w.device)
+    with torch.cuda.device(w.device), _timed("k_gemv", 2.0 * N * K):
+        check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), ptr(out.reshape(-1)), N, K,
+                              EPI[epilogue], 1 if out.dtype == torch.float32 else 0, stream_ptr(w.device)), "sc_gemv_f16")
+    return out

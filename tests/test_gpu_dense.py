@@ -112,3 +112,31 @@ def test_attention_online_softmax_rescale_branch():
     out = ops.attention(q, k, v, H, H, Dh, 0.125, False)
     ref = _attn_ref(q, k, v, H, H, Dh, 0.125, False)
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("N,K", [(3584, 3584), (1024, 3584), (152064, 3584), (3584, 18944), (130, 264)])
+def test_gemv_vs_torch_fp32(N, K):
+    w, x, b, r = _rand((N, K), 1, K ** -0.5), _rand((K,), 2), _rand((N,), 3), _rand((N,), 4)
+    y = ops.gemv(w, x, b, r)
+    ref = w.float() @ x.float() + b.float() + r.float()
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+    y32 = ops.gemv(w, x, out_f32=True)
+    torch.testing.assert_close(y32, w.float() @ x.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_gemv_swiglu():
+    K, I = 256, 384
+    x = _rand((K,), 1)
+    wg, wu = _rand((I, K), 2, 1 / 16), _rand((I, K), 3, 1 / 16)
+    wgu = torch.cat([wg.view(I // 2, 2, K), wu.view(I // 2, 2, K)], 1).reshape(2 * I, K).contiguous()
+    y = ops.gemv(wgu, x, epilogue="swiglu")
+    ref = torch.nn.functional.silu(wg.float() @ x.float()) * (wu.float() @ x.float())
+    torch.testing.assert_close(y.float(), ref, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("Sq,Skv,H,Dh,ns", [(7, 3000, 4, 128, 16), (1, 500, 2, 64, 4), (2, 200, 4, 64, 7), (7, 70, 4, 128, 2)])
+def test_attention_split_kv_equals_unsplit(Sq, Skv, H, Dh, ns):
+    q, k, v = _rand((1, Sq, H * Dh), 1), _rand((1, Skv, H * Dh), 2), _rand((1, Skv, H * Dh), 3)
+    a = ops.attention(q, k, v, H, H, Dh, Dh ** -0.5, False, nsplit=ns)
+    ref = _attn_ref(q, k, v, H, H, Dh, Dh ** -0.5, False)
+    torch.testing.assert_close(a.float(), ref, rtol=2e-3, atol=2e-3)
