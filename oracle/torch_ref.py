@@ -140,3 +140,33 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
         x = x + F.linear(m, sd[p + "mlp.down_proj.weight"])
     x = _rms(x, sd["model.norm.weight"], eps)
     return F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k-means in the reference's own formulation (utiles.py:294-318): [T,K,D] broadcast distances, boolean-mask updates.
+# Used (a) as a second, independent oracle against the golden vectors and (b) as the CPU-baseline timer of bench.py, because
+# this is the arithmetic the reference actually executes on a CPU (the C oracle restates the GPU reduction tree instead).
+# ---------------------------------------------------------------------------------------------------------
+def weighted_kmeans_reference_formula(X, K, init_idx, reseed_idx=None, weights=None, tol=1e-4, max_iter=10):
+    T = X.shape[0]
+    w = torch.ones(T, dtype=X.dtype) if weights is None else weights
+    C = X[torch.as_tensor(init_idx, dtype=torch.long)].clone()
+    rs = list(reseed_idx) if reseed_idx is not None else []
+    for i in range(max_iter):
+        d = ((X.unsqueeze(1) - C.unsqueeze(0)) ** 2).sum(dim=2).sqrt()
+        labels = torch.argmin(d, dim=1)
+        ws = torch.zeros_like(C)
+        wsum = torch.zeros(K, dtype=X.dtype)
+        for j in range(K):
+            m = labels == j
+            ws[j] = torch.sum(w[m, None] * X[m], dim=0)
+            wsum[j] = torch.sum(w[m])
+        mask = wsum > 0
+        newC = torch.zeros_like(ws)
+        newC[mask] = ws[mask] / wsum[mask, None]
+        if mask.sum() < K:
+            newC[~mask] = torch.stack([X[int(rs.pop(0))] for _ in range(K - int(mask.sum()))])
+        if torch.norm(C - newC, dim=1).sum() < tol:
+            break
+        C = newC
+    return C, labels, wsum, i

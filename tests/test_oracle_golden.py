@@ -65,3 +65,16 @@ def test_topk_oracle():
     q = docs[2].copy()
     idx, _ = oracle.topk(q, docs, 2, "cos")
     assert list(idx) == [2, 5]           # tie -> lowest index
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_reference_formula_restatement_matches_golden(path):
+    """oracle/torch_ref.weighted_kmeans_reference_formula (the [T,K,D] broadcast form the reference runs) vs the golden vectors."""
+    import torch
+    from oracle import torch_ref as R
+    d = np.load(path)
+    X = torch.from_numpy(d["X"]).reshape(d["X"].shape[0], -1)
+    w = torch.from_numpy(d["weights"]) if "weights" in d.files else None
+    C, labels, wsum, it = R.weighted_kmeans_reference_formula(X, int(d["K"]), d["init_idx"], d["reseed_idx"], w)
+    assert np.array_equal(labels.numpy(), d["labels"]) and it == int(d["exit_iter"])
+    np.testing.assert_allclose(C.numpy(), d["centroids"].reshape(int(d["K"]), -1), rtol=1e-5, atol=1e-6)
