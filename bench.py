@@ -260,9 +260,15 @@ def main():
     ms_step = dt / a.steps * 1e3
     value = a.frames * world * a.steps / dt
     n, ms, work = prof.get("k_gemm", (0, 0.0, 0.0))
+    traffic = None
+    try:        # HBM bytes per launch from the committed PMC passes of this same command (profiles/, see its `correction` note)
+        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_gemm256"]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
     roof = dict(bound="mfma", kernel="k_gemm256 (+k_gemm128 for M<1024 or N%256)", launches=n, avg_ms=round(ms / max(n, 1), 5),
                 achieved=round(work / max(ms, 1e-9) / 1e9, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
-                frac=round(work / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4), traffic=None)
+                frac=round(work / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4), traffic=traffic,
+                flops_per_launch=round(work / max(n, 1)))
     stages = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in prof.items()}
     if "kmeans_fit" in prof:
         kn, kms, kw = prof["kmeans_fit"]
