@@ -10,7 +10,8 @@
 //               (v_permlane32_swap / v_permlane16_swap + 4 shuffle levels: ~2.5 ops per value
 //               instead of 12) and written as one coalesced 256-byte line per group.
 //   km_reduce   fp64 two-level (32 segments) sum of the per-chunk partials.
-//   km_labels   argmin (first minimum), stable counting sort of rows by label, W[k].
+//   km_argmin   fp64 totals -> argmin (first minimum), one thread per row.
+//   km_order    single block: stable counting sort of rows by label (ballot ranks), W[k], empty-cluster ranks.
 //   km_update   one wave per chunk: per cluster, rows in ascending order, fp32 sequential
 //               weighted sum / W; shift partials for the convergence test.
 //   km_decide   sum_k ||C_i - C'||_2 < tol ? -> device-side `done` flag (no host round trip).
@@ -23,6 +24,7 @@ namespace {
 constexpr int CH = 512;      // columns per chunk = 64 lanes x 8 elements
 constexpr int NSEG = 32;     // fp64 segments
 constexpr int WPB = 4;       // waves per block in the streaming kernels
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
 
 struct KmState {
     int done, exit_iter, cur, reseed_pos, status, n_empty, pad0, pad1;
@@ -31,7 +33,11 @@ struct KmState {
 template <typename Tag> struct Raw8;
 template <> struct Raw8<ScF16> {
     uint4 a;
-    __device__ __forceinline__ void load(const void* b, size_t off) { a = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(b) + off); }
+    __device__ __forceinline__ void load(const void* b, size_t off) {        // X is streamed once per pass: non-temporal
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(reinterpret_cast<const _Float16*>(b) + off));
+        a = make_uint4(v[0], v[1], v[2], v[3]);
+    }
     __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); }
     __device__ __forceinline__ void unpack(float (&o)[8]) const {
         sc_h8 v = __builtin_bit_cast(sc_h8, a);
@@ -165,15 +171,16 @@ __global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X
             }
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                float a0 = 0.f, a1 = 0.f;
+                // packed fp32 math (v_pk_add_f32 / v_pk_fma_f32): component .x carries the even elements' accumulator, .y the odd
+                // ones' — exactly the SC-KM1 lane partial (each packed op is IEEE per component)
+                sc_f2 acc = {0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const float d0 = x[e] - cr[k][e];
-                    const float d1 = x[e + 1] - cr[k][e + 1];
-                    a0 = __builtin_fmaf(d0, d0, a0);
-                    a1 = __builtin_fmaf(d1, d1, a1);
+                    const sc_f2 xv = {x[e], x[e + 1]}, cv = {cr[k][e], cr[k][e + 1]};
+                    const sc_f2 d = xv - cv;
+                    acc = __builtin_elementwise_fma(d, d, acc);
                 }
-                p[tt * KB + k] = a0 + a1;
+                p[tt * KB + k] = acc.x + acc.y;
             }
         }
         butterfly64(p, lane);
@@ -200,54 +207,99 @@ __global__ void km_reduce(const float* __restrict__ partial, const KmState* __re
     int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
     if (hi > nchunks) hi = nchunks;
     double a = 0.0;
-    for (int64_t c = lo; c < hi; ++c) a += (double)partial[(size_t)c * I + item];
+    int64_t c = lo;
+    for (; c + 8 <= hi; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + u) * I + item];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; c < hi; ++c) a += (double)partial[(size_t)c * I + item];
     seg[(size_t)s * I + item] = a;
 }
 
-// single block: dist2 totals -> labels (first minimum) -> stable order by label, W[k], empties
-__global__ __launch_bounds__(256) void km_labels(const double* __restrict__ seg, KmState* __restrict__ st,
-                                                 const float* __restrict__ w, int* __restrict__ labels32,
-                                                 int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
-                                                 int* __restrict__ empty_rank, double* __restrict__ dist2_out, int T, int K,
-                                                 int check_done) {
+// dist2 totals -> labels (first minimum); one thread per row, rows spread over the grid
+__global__ __launch_bounds__(64) void km_argmin(const double* __restrict__ seg, const KmState* __restrict__ st, int* __restrict__ labels32,
+                                                double* __restrict__ dist2_out, int T, int K, int check_done) {
     if (check_done && st->done) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
     const size_t I = (size_t)T * K;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        int best = 0;
-        double bv = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double tot = 0.0;
-            for (int s = 0; s < NSEG; ++s) tot += seg[(size_t)s * I + (size_t)t * K + k];
-            if (dist2_out) dist2_out[(size_t)t * K + k] = tot;
-            if (k == 0 || tot < bv) { bv = tot; best = k; }
-        }
-        labels32[t] = best;
+    int best = 0;
+    double bv = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double part[NSEG];
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) part[s] = seg[(size_t)s * I + (size_t)t * K + k];       // independent loads, summed in order
+        double tot = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) tot += part[s];
+        if (dist2_out) dist2_out[(size_t)t * K + k] = tot;
+        if (k == 0 || tot < bv) { bv = tot; best = k; }
     }
+    labels32[t] = best;
+}
+
+// single block: stable counting sort of the rows by label (ballot ranks), W[k], empty-cluster ranks
+__global__ __launch_bounds__(1024) void km_order(KmState* __restrict__ st, const float* __restrict__ w, const int* __restrict__ labels32,
+                                                 int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
+                                                 int* __restrict__ empty_rank, int T, int K, int check_done) {
+    if (check_done && st->done) return;
+    extern __shared__ int sm[];               // counts[K] | wave_cnt[16]
+    int* counts = sm;
+    int* wcnt = sm + K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) counts[k] = 0;
     __syncthreads();
-    // counts + sequential fp32 weight sums (ascending t), one thread per cluster
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        int n = 0;
-        float ws = 0.f;
-        for (int t = 0; t < T; ++t)
-            if (labels32[t] == k) { ++n; ws = ws + (w ? w[t] : 1.0f); }
-        start[k + 1] = n;   // temporarily the count
-        W[k] = ws;
-    }
+    // pass 1: cluster sizes
+    for (int t = threadIdx.x; t < T; t += blockDim.x) atomicAdd(&counts[labels32[t]], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
-        start[0] = 0;
-        int ne = 0;
+        int acc = 0, ne = 0;
+        for (int k = 0; k < K; ++k) { start[k] = acc; acc += counts[k]; }
+        start[K] = acc;
         for (int k = 0; k < K; ++k) {
-            start[k + 1] += start[k];
-            empty_rank[k] = (W[k] > 0.f) ? -1 : ne++;
+            const bool empty = w ? false : (counts[k] == 0);        // unweighted: W = count (exact in any order); weighted: decided below
+            empty_rank[k] = empty ? ne++ : -1;
+            if (!w) W[k] = (float)counts[k];
         }
-        st->n_empty = ne;
+        if (!w) st->n_empty = ne;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        int pos = start[k];
-        for (int t = 0; t < T; ++t)
-            if (labels32[t] == k) order[pos++] = t;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) counts[k] = 0;            // becomes the running fill position per cluster
+    __syncthreads();
+    // pass 2: stable scatter, tiles of blockDim rows in ascending t; rank inside the tile by per-cluster ballots
+    for (int t0 = 0; t0 < T; t0 += blockDim.x) {
+        const int t = t0 + threadIdx.x;
+        const int lab = t < T ? labels32[t] : -1;
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(lab == k);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            if (lab == k) {
+                int before = 0;
+                for (int i = 0; i < wave; ++i) before += wcnt[i];
+                order[start[k] + counts[k] + before + __popcll(m & ((1ull << lane) - 1ull))] = t;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { int tot = 0; for (int i = 0; i < nw; ++i) tot += wcnt[i]; counts[k] += tot; }
+            __syncthreads();
+        }
+    }
+    // weighted: W[k] = sequential fp32 sum over the cluster's rows in ascending order (SC-KM1)
+    if (w) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            float ws = 0.f;
+            for (int i = start[k]; i < start[k + 1]; ++i) ws = ws + w[order[i]];
+            W[k] = ws;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int ne = 0;
+            for (int k = 0; k < K; ++k) empty_rank[k] = (W[k] > 0.f) ? -1 : ne++;
+            st->n_empty = ne;
+        }
     }
 }
 
@@ -280,6 +332,7 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
             for (int i0 = lo; i0 < hi; i0 += U) {
                 float x[U][8];
                 float wt[U];
+                Raw8<Tag> raw[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u;
@@ -287,23 +340,25 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
                         const int t = order[i];
                         wt[u] = w ? w[t] : 1.0f;
                         if (VEC) {
-                            if (active) sc_load8<Tag>(X, (size_t)t * (size_t)D + (size_t)col, x[u]);
-                            else {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
-                            }
+                            if (active) raw[u].load(X, (size_t)t * (size_t)D + (size_t)col);
+                            else raw[u].zero();
                         } else load8_guard<Tag>(X, (size_t)t * (size_t)D, col, D, x[u]);
                     } else {
                         wt[u] = 0.f;
+                        raw[u].zero();
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
                     }
+                }
+                if (VEC) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) raw[u].unpack(x[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (i0 + u < hi) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) cn[e] = cn[e] + wt[u] * x[u][e];   // mul, then add: no contraction
+                        for (int e = 0; e < 8; ++e) cn[e] = w ? cn[e] + wt[u] * x[u][e] : cn[e] + x[u][e];   // mul, then add (1.0f * x == x exactly)
                     }
                 }
             }
@@ -363,7 +418,15 @@ __global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart
             int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
             if (hi > nchunks) hi = nchunks;
             double a = 0.0;
-            for (int64_t c = lo; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
+            int64_t c = lo;
+            for (; c + 8 <= hi; c += 8) {                 // 8 independent loads in flight, added in ascending chunk order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = dpart[(size_t)(c + u) * K + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
+            }
+            for (; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
             segs[s * 64 + (k - kb)] = a;
         }
         __syncthreads();
@@ -492,8 +555,8 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     for (int it = 0; it < max_iter; ++it) {
         launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
         hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 1);
-        hipLaunchKernelGGL(km_labels, dim3(1), dim3(256), 0, s, w.seg, w.st, wts, w.labels32, w.order, w.start, w.W,
-                           w.empty_rank, (double*)nullptr, T, K, 1);
+        hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
+        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
         if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
                                     w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch);
         else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
@@ -515,8 +578,7 @@ int assign_impl(const void* X, int T, int64_t D, int K, const float* C, int64_t*
     w.Ca = const_cast<float*>(C);   // read-only use: state.cur == 0 selects Ca
     launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
     hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 0);
-    hipLaunchKernelGGL(km_labels, dim3(1), dim3(256), 0, s, w.seg, w.st, (const float*)nullptr, w.labels32, w.order, w.start,
-                       w.W, w.empty_rank, dist2, T, K, 0);
+    hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, dist2, T, K, 0);
     hipLaunchKernelGGL(km_labels_out, dim3((T + 255) / 256), dim3(256), 0, s, w.labels32, labels, T);
     SC_CHECK_LAUNCH("sc_kmeans_assign");
     return SC_OK;
