@@ -173,17 +173,26 @@ constexpr int NSTAGE2 = 4;
 
 __device__ __forceinline__ int swzF(int x) { return (0x78 >> (2 * (x & 3))) & 3; }
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
-                                                    const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
-                                                    void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
-                                                    int a_grp_stride, int a_grp_off) {
+// WR = wave rows: 2 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, one workgroup per CU, DMA 3 steps ahead);
+//                  1 -> 128x256 tile, 4 waves, 3-slot ring (72 KiB, TWO workgroups per CU, DMA 2 steps ahead): for short-K GEMMs
+//                       (ViT, K = 1024: 32 steps) one workgroup's prologue / epilogue then overlaps the other's main loop.
+template <int EPI, bool OUT_F32, int WR>
+__global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                         const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
+                                                         int a_grp_stride, int a_grp_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = WR * 256;                    // threads
+    constexpr int NS = WR == 2 ? 4 : 3;             // ring slots
+    constexpr int DIST = NS - 1;                    // DMA issue distance in K-steps
+    constexpr int BMx = 128 * WR;
+    constexpr int AH = BMx * BK2 * 2;               // A bytes per stage
+    constexpr int STG = AH + HALF2;                 // + W bytes per stage (256 rows)
+    constexpr int GW = 4 / WR;                      // W granules per thread per stage (A: always 2)
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    // grouped raster: GM tile-rows per group, tile-row index fastest, so the ~32 tiles an XCD runs concurrently form a
-    // GM x (32/GM) patch (12 operand panels through its L2 instead of 3 + tilesN)
+    // grouped raster: GM tile-rows per group, tile-row index fastest, so the tiles an XCD runs concurrently form a compact patch
     constexpr int GM = 8;
     const int tilesM = nwg / tilesN;
     const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
@@ -194,37 +203,50 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    // staging: granule q = j*512 + tid -> row q>>2, physical slot q&3
+    // staging: granule q = j*NT + tid -> row q>>2, physical slot q&3
     const _Float16* a_src[2];
-    const _Float16* w_src[2];
+    const _Float16* w_src[GW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int q = j * 512 + tid;
+        const int q = j * NT + tid;
         const int r = q >> 2;
         const int sl = (q & 3) ^ swzF(r >> 2);
-        int ar = tm * BM2 + r;
+        int ar = tm * BMx + r;
         ar = ar < M ? ar : M - 1;
         if (a_grp > 0) ar = (ar / a_grp) * a_grp_stride + a_grp_off + (ar % a_grp);
         a_src[j] = A + (size_t)ar * (size_t)lda + sl * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < GW; ++j) {
+        const int q = j * NT + tid;
+        const int r = q >> 2;
+        const int sl = (q & 3) ^ swzF(r >> 2);
         w_src[j] = W + (size_t)(tn * BN2 + r) * (size_t)K + sl * 8;
     }
+    auto slot_of = [&](int ks) { return NS == 4 ? (ks & 3) : (ks % 3); };
     auto issue_w = [&](int ks) {
-        char* base = smem + (ks & 3) * STAGE2 + HALF2;
+        char* base = smem + slot_of(ks) * STG + AH;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(w_src[j] + ks * BK2), (lds_ptr_t)(base + (j * 512 + wave * 64) * 16), 16, 0, 0);
+        for (int j = 0; j < GW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(w_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
     };
     auto issue_a = [&](int ks) {
-        char* base = smem + (ks & 3) * STAGE2;
+        char* base = smem + slot_of(ks) * STG;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + ks * BK2), (lds_ptr_t)(base + (j * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    // wait until at most `steps_in_flight` K-steps of this thread's DMA are outstanding (2 + GW issues per step)
+    auto wait_steps = [&](int steps_in_flight) {
+        if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (steps_in_flight == 1) { if (GW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if (GW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
     };
 
     const int rl = lane & 15, g = lane >> 4;
     const int frag = rl * 64 + ((g ^ swzF(rl >> 2)) << 4);
     const int a_off = wr * 128 * 64 + frag;                 // + half*4096 + mi*1024
-    const int b_off = HALF2 + wc * 64 * 64 + frag;          // + ni*1024
+    const int b_off = AH + wc * 64 * 64 + frag;             // + ni*1024
 
     sc_f4 acc[8][4];
 #pragma unroll
@@ -233,13 +255,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__
         for (int j = 0; j < 4; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK2;
-    // ---- prologue: steps 0..2 in flight, step 0 landed for every wave, first fragments in registers ----
+    // ---- prologue: steps 0..DIST-1 in flight, step 0 landed for every wave, first fragments in registers ----
     issue_w(0); issue_a(0);
     if (nk > 1) { issue_w(1); issue_a(1); }
-    if (nk > 2) { issue_w(2); issue_a(2); }
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DIST > 2 && nk > 2) { issue_w(2); issue_a(2); }
+    wait_steps((nk < DIST ? nk : DIST) - 1);
     __builtin_amdgcn_s_barrier();
     // fragment sets A / B ping-pong between consecutive K-steps (no register copies)
     sc_h8 aloA[4], ahiA[4], bcA[4], aloB[4], ahiB[4], bcB[4];
@@ -250,22 +270,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__
         ahiA[i] = *reinterpret_cast<const sc_h8*>(smem + a_off + 4096 + i * 1024);
     }
     // one K-step: multiply this step's fragments (alo, ahi, bc).  After the barrier that publishes step ks+1, its 12 fragment
-    // reads and the 4 DMA issues of step ks+3 are INTERLEAVED one-per-MFMA into the second MFMA cluster
+    // reads and the DMA issues of step ks+DIST are INTERLEAVED one-per-MFMA into the second MFMA cluster
     // (sched_group_barrier), so no wave ever sits in a load-issue burst while its SIMD's matrix pipe idles.
     auto kstep = [&](auto sid, int ks, bool steady, sc_h8(&alo)[4], sc_h8(&ahi)[4], sc_h8(&bc)[4], sc_h8(&alo_n)[4], sc_h8(&ahi_n)[4], sc_h8(&bn)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], alo[i], acc[i][j], 0, 0, 0);
-        // step ks+1 must have landed for everyone; slot (ks-1)&3 is free after this barrier
-        if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // step ks+1 must have landed for everyone (steps ks+2 .. ks+DIST-1 may stay in flight); slot of step ks-1 is free afterwards
+        if (steady) wait_steps(DIST - 2);
+        else { const int newest = (ks + DIST - 1) < (nk - 1) ? (ks + DIST - 1) : (nk - 1); wait_steps(newest - (ks + 1)); }
         __builtin_amdgcn_s_barrier();
-        if (steady) { issue_w(ks + 3); issue_a(ks + 3); }
-        else if (ks + 3 < nk) { issue_w(ks + 3); issue_a(ks + 3); }
+        if (steady) { issue_w(ks + DIST); issue_a(ks + DIST); }
+        else if (ks + DIST < nk) { issue_w(ks + DIST); issue_a(ks + DIST); }
         {   // unconditional (after the last step the fragments are simply unused): a branch here makes hipcc drain lgkmcnt(0)
-            const char* sn = smem + ((ks + 1) & 3) * STAGE2;
+            const char* sn = smem + slot_of(ks + 1) * STG;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 bn[i] = *reinterpret_cast<const sc_h8*>(sn + b_off + i * 1024);
@@ -281,13 +300,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__
         if (steady) {
             constexpr int SID = decltype(sid)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x020, 1, SID); }
+            for (int i = 0; i < 2 + GW; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x020, 1, SID); }
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, 1, SID); }
+            for (int i = 0; i < 12 - (GW - 2); ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, 1, SID); }
         }
     };
     int ks = 0;
-    for (; ks + 4 < nk; ks += 2) {                       // steady state: both steps of the pair still issue DMA
+    for (; ks + 1 + DIST < nk; ks += 2) {                // steady state: both steps of the pair still issue DMA
         kstep(std::integral_constant<int, 0>{}, ks, true, aloA, ahiA, bcA, aloB, ahiB, bcB);
         kstep(std::integral_constant<int, 1>{}, ks + 1, true, aloB, ahiB, bcB, aloA, ahiA, bcA);
     }
@@ -297,41 +316,98 @@ __global__ __launch_bounds__(512, 2) void k_gemm256(const _Float16* __restrict__
     }
     if (ks < nk) kstep(std::integral_constant<int, 4>{}, ks, false, aloA, ahiA, bcA, aloB, ahiB, bcB);
 
-    // ---- epilogue (same lane ownership as v1: 4 consecutive columns of one row) ----
-    const int m0 = tm * BM2 + wr * 128, n0 = tn * BN2 + wc * 64;
+    // ---- epilogue.  Each lane owns C[m = m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3]; bias / activation / residual are applied in
+    // fp32 in that ownership.  The fp16 results are then exchanged between the four 16-lane rows of the wave with
+    // v_permlane16_swap (and v_permlane32_swap for SwiGLU) so that every lane holds 16 contiguous bytes of one output row and the
+    // tile leaves as dwordx4 stores: 16 (8 for SwiGLU) store instructions per lane instead of 32 — the store tail of a
+    // one-workgroup-per-CU GEMM is store-ISSUE bound (guide T21; K-sweep: ~15 us fixed per tile before).
+    const int m0 = tm * BMx + wr * 128, n0 = tn * BN2 + wc * 64;
+    auto pack2 = [](float a, float b) -> unsigned { const sc_h2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); };
+    if (OUT_F32) {
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj) {
-        const int n = n0 + nj * 16 + g * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            sc_h4 b4 = *reinterpret_cast<const sc_h4*>(bias + n);
+        for (int nj = 0; nj < 4; ++nj) {
+            const int n = n0 + nj * 16 + g * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) { const sc_h4 b4 = *reinterpret_cast<const sc_h4*>(bias + n); for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (float)b4[e];
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + mi * 16 + rl;
-            if (m < M) {
-                if (EPI == SC_EPI_SWIGLU) {
-                    const float g0 = acc[mi][nj][0] + bv[0], g1 = acc[mi][nj][1] + bv[1];
-                    const float u0 = acc[mi][nj][2] + bv[2], u1 = acc[mi][nj][3] + bv[3];
-                    const sc_h2 o = {(_Float16)(g0 / (1.0f + __expf(-g0)) * u0), (_Float16)(g1 / (1.0f + __expf(-g1)) * u1)};
-                    *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
-                } else {
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = m0 + mi * 16 + rl;
+                if (m < M) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[e], EPI);
-                    if (R) {
-                        sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n);
+                    if (R) { const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n); for (int e = 0; e < 4; ++e) v[e] += (float)r4[e]; }
+                    *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+    } else if (EPI == SC_EPI_SWIGLU) {
+        float bv[4][4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const int n = n0 + nj * 16 + g * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[nj][e] = bias ? (float)bias[n + e] : 0.f;
+        }
+        _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + mi * 16 + rl;
+            unsigned d[4];                                      // d[nj] = (silu(g0)*u0, silu(g1)*u1) of output columns (n0>>1) + nj*8 + g*2
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
+                const float g0 = acc[mi][nj][0] + bv[nj][0], g1 = acc[mi][nj][1] + bv[nj][1];
+                const float u0 = acc[mi][nj][2] + bv[nj][2], u1 = acc[mi][nj][3] + bv[nj][3];
+                d[nj] = pack2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+            }
+            // level 1 (rows of 16 lanes): lane row g -> 4 contiguous columns of nj = (g&1) + {0,2}
+            const auto p0 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+            const auto p1 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+            // level 2 (wave halves): lane row g -> the 8 contiguous columns of nj = g
+            const auto q0 = __builtin_amdgcn_permlane32_swap(p0[0], p1[0], false, false);
+            const auto q1 = __builtin_amdgcn_permlane32_swap(p0[1], p1[1], false, false);
+            if (m < M) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const u4v o = {q0[0], q1[0], q0[1], q1[1]};
+                *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + (n0 >> 1) + g * 8) = o;
+            }
+        }
+    } else {
+        float bv[4][4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const int n = n0 + nj * 16 + g * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[nj][e] = bias ? (float)bias[n + e] : 0.f;
+        }
+        _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + mi * 16 + rl;
+            const bool live = m < M;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned lo[2], hi[2];                          // packed halves of nj = 2pr (lo) and 2pr+1 (hi): [0] = cols +0,+1  [1] = cols +2,+3
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nj = 2 * pr + h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[nj][e], EPI);
+                    if (R && live) {
+                        const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n0 + nj * 16 + g * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
                     }
-                    if (OUT_F32) {
-                        *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        sc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = o;
-                    }
+                    (h ? hi : lo)[0] = pack2(v[0], v[1]);
+                    (h ? hi : lo)[1] = pack2(v[2], v[3]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                if (live) {                                     // lane row g: 8 contiguous columns of nj = 2pr + (g&1), starting at (g>>1)*8
+                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                    const u4v o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + n0 + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8) = o;
                 }
             }
         }
@@ -343,23 +419,26 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
     static int force = -1;                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
-    const bool big = force == 256 || (force != 128 && M >= 1024);
-    if (big && N % BN2 == 0 && K % BK2 == 0) {
-        const int tM = (M + BM2 - 1) / BM2, tN = N / BN2;
-        const dim3 grid2((unsigned)(tM * tN)), block2(512);
-        const size_t lds2 = NSTAGE2 * STAGE2;
-        static bool attr_done[8] = {false, false, false, false, false, false, false, false};
-        if (!attr_done[EPI * 2 + (out_f32 ? 1 : 0)]) {
-            (void)hipFuncSetAttribute(out_f32 ? (const void*)k_gemm256<EPI, true> : (const void*)k_gemm256<EPI, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr_done[EPI * 2 + (out_f32 ? 1 : 0)] = true;
-        }
-        if (out_f32)
-            hipLaunchKernelGGL((k_gemm256<EPI, true>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off);
-        else
-            hipLaunchKernelGGL((k_gemm256<EPI, false>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off);
+    const bool big = force == 256 || force == 2561 || (force != 128 && M >= 1024);
+    const bool wide_ok = out_f32 || (ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);      // 16-byte epilogue stores
+    if (big && wide_ok && N % BN2 == 0 && K % BK2 == 0) {
+        // 256x256 tiles; the 128x256 / two-workgroups-per-CU variant is kept for A/B runs (SC_GEMM_KERNEL=2561)
+        const bool half = force == 2561;        // measured: the 256x256 tile wins at every K once the store tail is widened (K-sweep in profiles)
+        const int bm = half ? 128 : 256;
+        const int tM = (M + bm - 1) / bm, tN = N / BN2;
+        const dim3 grid2((unsigned)(tM * tN)), block2(half ? 256 : 512);
+        const size_t lds2 = half ? 3 * (128 * BK2 * 2 + HALF2) : 4 * STAGE2;
+        const void* fn = half ? (out_f32 ? (const void*)k_gemm256<EPI, true, 1> : (const void*)k_gemm256<EPI, false, 1>)
+                              : (out_f32 ? (const void*)k_gemm256<EPI, true, 2> : (const void*)k_gemm256<EPI, false, 2>);
+        static bool attr_done[16] = {};
+        const int ai = EPI * 4 + (out_f32 ? 2 : 0) + (half ? 1 : 0);
+        if (!attr_done[ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[ai] = true; }
+#define SC_L256(F32, WRV)                                                                                                                 \
+        hipLaunchKernelGGL((k_gemm256<EPI, F32, WRV>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
+                           (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off)
+        if (half) { if (out_f32) SC_L256(true, 1); else SC_L256(false, 1); }
+        else { if (out_f32) SC_L256(true, 2); else SC_L256(false, 2); }
+#undef SC_L256
         SC_CHECK_LAUNCH("sc_gemm_f16");
         return SC_OK;
     }
