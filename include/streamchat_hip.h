@@ -126,9 +126,11 @@ int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const v
 int sc_vit_embed_ln_f16(const void* patch, const void* cls, const void* pos, const void* gamma,
                         const void* beta, float eps, void* out, int N, int P, int D, sc_stream_t stream);
 /* Decode-time matrix-vector product y[N] = W[N,K] . x[K] (+ bias) (+ residual): weights streamed once (HBM-bound).
- * epilogue SC_EPI_NONE or SC_EPI_SWIGLU (interleaved gate/up rows, y has N/2 entries).  K % 8 == 0. */
+ * epilogue SC_EPI_NONE or SC_EPI_SWIGLU (interleaved gate/up rows, y has N/2 entries).  K % 8 == 0.
+ * y_row (optional, device int32[1]): write to row y_row[0] of a [rows, y_ld] fp16 buffer starting at y (KV-cache append at a
+ * device-resident position, so a whole decode step can be captured once in a hipGraph and replayed). */
 int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K,
-                int epilogue, int out_f32, sc_stream_t stream);
+                int epilogue, int out_f32, const int32_t* y_row, int y_ld, sc_stream_t stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim, fp32 statistics; [rows, cols] fp16, cols % 8 == 0,
  * cols <= 4096. */
 int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y,
@@ -144,6 +146,8 @@ int sc_gather_rows_f16(const int32_t* ids, const void* table, void* out, int row
                        sc_stream_t stream);
 int sc_rope_f16(void* x, int ld, const int32_t* positions, int pos0, int rows, int heads, int Dh, float theta,
                 sc_stream_t stream);
+/* RoPE on ONE row of a [rows, ld] buffer; the row number (= token position) is read from device memory (graph-replayable). */
+int sc_rope_row_f16(void* buf, int ld, const int32_t* row_index, int heads, int Dh, float theta, sc_stream_t stream);
 /* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
  * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
  *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)
@@ -162,10 +166,14 @@ int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L
  *   causal: 0 = full; 1 = causal with the Sq queries aligned to the END of the Skv keys
  *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {32, 64, 128}.
  *   nsplit > 1: split-KV ("flash-decoding") for few queries over a long cache — the key range is cut into nsplit slices
- *   processed by separate workgroups and merged; needs ws of B*Hq*Sq*nsplit*(Dh+2)*4 bytes.  nsplit = 1: ws may be NULL. */
+ *   processed by separate workgroups and merged; needs ws of B*Hq*Sq*nsplit*(Dh+2)*4 bytes.  nsplit = 1: ws may be NULL.
+ *   q_head_stride / o_head_stride (elements; 0 = Dh): distance between consecutive heads inside a q / out row.  With
+ *   ldq = Dh and q_head_stride = G*Dh the G query heads of a GQA group become G query ROWS of one KV head without any copy
+ *   (decode: every K/V byte is then read once for the whole group). */
 int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                      int ldo, int B, int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal,
-                     const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, sc_stream_t stream);
+                     const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
+                     int o_head_stride, sc_stream_t stream);
 
 #ifdef __cplusplus
 }

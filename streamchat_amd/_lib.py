@@ -29,15 +29,16 @@ SIGNATURES = {
     "sc_gemm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p]),
     "sc_vit_embed_ln_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "sc_gemv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sc_gemv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_layernorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_rmsnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_float, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                                 c_float, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "sc_bert_embed_ln_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_pool_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_rope_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "sc_rope_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_sim_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }

@@ -31,7 +31,7 @@ template <int DH, int QB, bool CAUSAL>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
                                               int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
-                                              float* __restrict__ part, int nsplit, int B) {
+                                              float* __restrict__ part, int nsplit, int B, int q_hs, int o_hs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KVT * DH * 2;            // bytes per K (or V) tile
     constexpr int STAGE = 2 * TILE;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     for (int qb = 0; qb < QB; ++qb) {
         int qr = qw0 + qb * 16 + rl;
         qr = qr < Sq ? qr : Sq - 1;
-        const _Float16* qp = Q + ((size_t)b * Sq + qr) * (size_t)ldq + h * DH + g * 8;
+        const _Float16* qp = Q + ((size_t)b * Sq + qr) * (size_t)ldq + h * q_hs + g * 8;
 #pragma unroll
         for (int ds = 0; ds < DS; ++ds) qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
     }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 if (g == 0) { pp[DH] = m_run[qb]; pp[DH + 1] = l; }
             }
         } else if (qr < Sq) {
-            _Float16* op = O + ((size_t)b * Sq + qr) * (size_t)ldo + h * DH + g * 4;
+            _Float16* op = O + ((size_t)b * Sq + qr) * (size_t)ldo + h * o_hs + g * 4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const sc_h4 v = {(_Float16)(o[db][qb][0] * inv), (_Float16)(o[db][qb][1] * inv), (_Float16)(o[db][qb][2] * inv),
@@ -272,28 +272,50 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     }
 }
 
-// merge of the split-KV partials: out = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)
+// merge of the split-KV partials: out = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).  One workgroup (DH threads) per
+// (batch, head, query): the split weights are computed once by the first wave (one lane per split), then every thread owns one
+// output dimension and sums the weighted partials with independent loads.
 template <int DH>
-__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit) {
+__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit, int o_hs) {
+    __shared__ float wgt[1024];
+    __shared__ float inv_den;
     const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
     const int q = row % Sq, bh = row / Sq, h = bh % Hq, b = bh / Hq;
-    const int d = threadIdx.x;
     const float* pp = part + (size_t)row * nsplit * (DH + 2);
-    float M = -INFINITY;
-    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, pp[i * (DH + 2) + DH]);
-    float num = 0.f, den = 0.f;
-    for (int i = 0; i < nsplit; ++i) {
-        const float m = pp[i * (DH + 2) + DH];
-        const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
-        num += pp[i * (DH + 2) + d] * w;
-        den += pp[i * (DH + 2) + DH + 1] * w;
+    if (threadIdx.x < 64) {
+        float M = -INFINITY;
+        for (int i = threadIdx.x; i < nsplit; i += 64) M = fmaxf(M, pp[i * (DH + 2) + DH]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) M = fmaxf(M, __shfl_xor(M, s, 64));
+        float den = 0.f;
+        for (int i = threadIdx.x; i < nsplit; i += 64) {
+            const float m = pp[i * (DH + 2) + DH];
+            const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+            wgt[i] = w;
+            den += pp[i * (DH + 2) + DH + 1] * w;
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) den += __shfl_xor(den, s, 64);
+        if (threadIdx.x == 0) inv_den = den > 0.f ? 1.0f / den : 0.f;
     }
-    O[((size_t)b * Sq + q) * (size_t)ldo + h * DH + d] = (_Float16)(den > 0.f ? num / den : 0.f);
+    __syncthreads();
+    const int d = threadIdx.x;
+    float num = 0.f;
+    int i = 0;
+    for (; i + 8 <= nsplit; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(i + u) * (DH + 2) + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) num += v[u] * wgt[i + u];
+    }
+    for (; i < nsplit; ++i) num += pp[i * (DH + 2) + d] * wgt[i];
+    O[((size_t)b * Sq + q) * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
 }
 
 template <int DH, int QB>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
-                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, hipStream_t s) {
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, hipStream_t s) {
     const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16), G = Hq / Hkv;
     const int npairs = nqb * Hkv * B;
     const dim3 grid((unsigned)(((npairs + 7) / 8) * 8 * G * nsplit)), block(256);
@@ -301,11 +323,11 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
     const float sl2 = scale * 1.4426950408889634f;
     if (causal)
         hipLaunchKernelGGL((k_attn<DH, QB, true>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs);
     else
         hipLaunchKernelGGL((k_attn<DH, QB, false>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B);
-    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs);
+    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs);
     SC_CHECK_LAUNCH("sc_attention_f16");
     return SC_OK;
 }
@@ -314,7 +336,7 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
 
 extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
                                 int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
-                                int nsplit, void* ws, size_t ws_bytes, sc_stream_t stream) {
+                                int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, sc_stream_t stream) {
     SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
     SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
     SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
@@ -330,7 +352,9 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
         if (!ws || ws_bytes < need) return sc_fail(SC_ERR_WORKSPACE, "sc_attention_f16: split-KV workspace %zu < required %zu", ws_bytes, need);
         part = (float*)ws;
     }
-    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
-    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
-    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, s);
+    const int qhs = q_head_stride > 0 ? q_head_stride : Dh, ohs = o_head_stride > 0 ? o_head_stride : Dh;
+    SC_REQUIRE(qhs % 8 == 0 && ohs % 4 == 0, "sc_attention_f16: head strides must be multiples of 8 (q) / 4 (out)");
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
 }

@@ -8,11 +8,13 @@
 
 namespace {
 
-constexpr int RPW = 4;     // rows per wave
 
-template <bool SWIGLU, bool OUT_F32>
+template <bool SWIGLU, bool OUT_F32, int RPW>
 __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
-                                              const _Float16* __restrict__ res, void* __restrict__ y, int N, int K) {
+                                              const _Float16* __restrict__ res, void* __restrict__ y_base, int N, int K,
+                                              const int* __restrict__ y_row, int y_ld) {
+    // optional dynamic output row (KV-cache append at a device-resident position: keeps a decode step hipGraph-replayable)
+    void* y = y_row ? (void*)(reinterpret_cast<_Float16*>(y_base) + (size_t)y_row[0] * (size_t)y_ld) : y_base;
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= N) return;
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
         for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
     }
     if (lane == 0) {
-        if (SWIGLU) {          // rows (g g u u): two outputs per 4 rows
-            const float g0 = acc[0], g1 = acc[1], u0 = acc[2], u1 = acc[3];
+        if (SWIGLU) {          // rows (g g u u): two outputs per 4 rows (RPW == 4)
+            const float g0 = acc[0], g1 = acc[RPW > 1 ? 1 : 0], u0 = acc[RPW > 2 ? 2 : 0], u1 = acc[RPW > 3 ? 3 : 0];
             _Float16* o = reinterpret_cast<_Float16*>(y) + (row0 >> 1);
             o[0] = (_Float16)(g0 / (1.0f + __expf(-g0)) * u0);
             o[1] = (_Float16)(g1 / (1.0f + __expf(-g1)) * u1);
@@ -64,18 +66,25 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
 }  // namespace
 
 extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K, int epilogue,
-                           int out_f32, sc_stream_t stream) {
+                           int out_f32, const int32_t* y_row, int y_ld, sc_stream_t stream) {
     SC_REQUIRE(W && x && y, "sc_gemv_f16: null pointer argument");
     SC_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "sc_gemv_f16: K must be a positive multiple of 8");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "sc_gemv_f16: W and x must be 16-byte aligned");
     SC_REQUIRE(epilogue == SC_EPI_NONE || epilogue == SC_EPI_SWIGLU, "sc_gemv_f16: epilogue must be NONE or SWIGLU");
+    SC_REQUIRE(!y_row || (!out_f32 && y_ld > 0), "sc_gemv_f16: a dynamic output row needs fp16 output and y_ld > 0");
     SC_REQUIRE(epilogue != SC_EPI_SWIGLU || (N % 4 == 0 && !bias && !residual && !out_f32), "sc_gemv_f16: SwiGLU needs N % 4 == 0, no bias/residual, fp16 out");
-    const dim3 grid((unsigned)((N + 4 * RPW - 1) / (4 * RPW))), block(256);
     hipStream_t s = (hipStream_t)stream;
     const _Float16 *w = (const _Float16*)W, *xx = (const _Float16*)x, *b = (const _Float16*)bias, *r = (const _Float16*)residual;
-    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false>), grid, block, 0, s, w, xx, b, r, y, N, K);
-    else if (out_f32) hipLaunchKernelGGL((k_gemv<false, true>), grid, block, 0, s, w, xx, b, r, y, N, K);
-    else hipLaunchKernelGGL((k_gemv<false, false>), grid, block, 0, s, w, xx, b, r, y, N, K);
+    // rows per wave: 4 amortises the x loads when there are plenty of rows; 1 keeps >= ~900 workgroups in flight for the
+    // 3584-row projections (224 workgroups at 4 rows/wave left most CUs with a single latency-bound workgroup)
+    const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
+    const int rpw = few ? 1 : 4;
+    const dim3 grid((unsigned)((N + 4 * rpw - 1) / (4 * rpw))), block(256);
+    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
+    else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
+                        else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld); }
+    else { if (few) hipLaunchKernelGGL((k_gemv<false, false, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
+           else hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld); }
     SC_CHECK_LAUNCH("sc_gemv_f16");
     return SC_OK;
 }

@@ -52,7 +52,44 @@ __global__ __launch_bounds__(256) void k_rope(_Float16* __restrict__ x, int ld, 
     }
 }
 
+// single-row variant for decode: row (= position) read from device memory
+__global__ __launch_bounds__(256) void k_rope_row(_Float16* __restrict__ x, int ld, const int* __restrict__ row_index, int heads, int Dh, float log2_theta) {
+    const int half = Dh / 2, per_row = heads * (half / 4);
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= per_row) return;
+    const int row = row_index[0];
+    const int h = rem / (half / 4), i0 = (rem - h * (half / 4)) * 4;
+    const float p = (float)row;
+    _Float16* base = x + (size_t)row * ld + h * Dh;
+    sc_h4 a = *reinterpret_cast<const sc_h4*>(base + i0);
+    sc_h4 b = *reinterpret_cast<const sc_h4*>(base + half + i0);
+    sc_h4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float inv_freq = exp2f(-log2_theta * (float)(2 * (i0 + e)) / (float)Dh);
+        float sn, cs;
+        sincosf(p * inv_freq, &sn, &cs);
+        const _Float16 c16 = (_Float16)cs, s16 = (_Float16)sn;
+        const _Float16 t1 = (_Float16)((float)a[e] * (float)c16), t2 = (_Float16)((float)b[e] * (float)s16);
+        const _Float16 t3 = (_Float16)((float)b[e] * (float)c16), t4 = (_Float16)((float)a[e] * (float)s16);
+        oa[e] = (_Float16)((float)t1 - (float)t2);
+        ob[e] = (_Float16)((float)t3 + (float)t4);
+    }
+    *reinterpret_cast<sc_h4*>(base + i0) = oa;
+    *reinterpret_cast<sc_h4*>(base + half + i0) = ob;
+}
+
 }  // namespace
+
+extern "C" int sc_rope_row_f16(void* buf, int ld, const int32_t* row_index, int heads, int Dh, float theta, sc_stream_t stream) {
+    SC_REQUIRE(buf && row_index, "sc_rope_row_f16: null pointer argument");
+    SC_REQUIRE(heads > 0 && Dh > 0 && Dh % 8 == 0 && ld >= heads * Dh && ld % 4 == 0 && theta > 1.f, "sc_rope_row_f16: bad sizes");
+    const int per_row = heads * (Dh / 8);
+    hipLaunchKernelGGL(k_rope_row, dim3((unsigned)((per_row + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (_Float16*)buf, ld, row_index, heads, Dh,
+                       log2f(theta));
+    SC_CHECK_LAUNCH("sc_rope_row_f16");
+    return SC_OK;
+}
 
 extern "C" int sc_gather_rows_f16(const int32_t* ids, const void* table, void* out, int rows, int H, int ldo, int vocab, sc_stream_t stream) {
     SC_REQUIRE(ids && table && out, "sc_gather_rows_f16: null pointer argument");

@@ -181,10 +181,10 @@ def _decode_one(self, embeds):
         ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
         ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
         ck = self.cache[l][:S]
-        qp = q.view(c.kv_heads, G, Dh).transpose(0, 1).reshape(1, G, dkv).contiguous()          # heads of a KV group -> query rows
-        op = ops.attention(qp, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,
-                           causal=False, nsplit=nsplit)
-        att = op.view(G, c.kv_heads, Dh).transpose(0, 1).reshape(1, dq).contiguous()
+        # the G heads of a KV group become G query ROWS of that KV head purely by addressing (row stride Dh, head stride G*Dh)
+        qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
+        att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
+                            nsplit=nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
         h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
         x = ops.rmsnorm(h2, L["ln2"], c.eps)
         m = ops.gemv(L["wgu"], x, None, epilogue="swiglu")
@@ -195,6 +195,77 @@ def _decode_one(self, embeds):
 
 
 Qwen2Model._decode_one = _decode_one
+
+
+class DecodeGraph:
+    """Greedy batch-1 decode captured ONCE as a hipGraph and replayed per token (the 13 launches x layers of a decode step are
+    launch-bound from Python: cdna guide "capture launch-bound inner loops in hipGraphs").  Everything that changes from token to
+    token lives in device memory: the input token id, the cache position (GEMV / RoPE write the KV row `pos`), the valid key count
+    (attention takes it as kv_len over the full-capacity cache view), and the output token ring."""
+
+    def __init__(self, lm, max_new_tokens=1024, nsplit=64):
+        self.lm, self.nsplit = lm, nsplit
+        dev = lm.device
+        self.tok = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.len = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.out = torch.zeros(max_new_tokens, dtype=torch.int64, device=dev)
+        self.graph = None
+
+    def _body(self):
+        lm, c = self.lm, self.lm.cfg
+        dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
+        h = ops.gather_rows(self.tok, lm.embed)
+        for l, L in enumerate(lm.L):
+            x = ops.rmsnorm(h, L["ln1"], c.eps)
+            q = ops.gemv(L["wq"], x, L["bq"]).view(1, dq)
+            ops.gemv(L["wkv"], x, L["bkv"], out=lm.cache[l], out_row=self.pos)               # KV row `pos` of the cache
+            ops.rope_(q, c.heads, Dh, c.rope_theta, positions=self.pos)
+            ops.rope_row_(lm.cache[l], self.pos, c.kv_heads, Dh, c.rope_theta)
+            ck = lm.cache[l]
+            qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
+            att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
+                                kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
+            h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
+            x = ops.rmsnorm(h2, L["ln2"], c.eps)
+            m = ops.gemv(L["wgu"], x, None, epilogue="swiglu")
+            h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
+        logits = ops.gemv(lm.lm_head, ops.rmsnorm(h, lm.norm, c.eps), None, out_f32=True)
+        nxt = torch.argmax(logits).reshape(1)
+        self.out.index_copy_(0, self.cnt, nxt)
+        self.tok.copy_(nxt)
+        self.pos.add_(1); self.len.add_(1); self.cnt.add_(1)
+        return logits
+
+    def start(self, first_token: int):
+        """position the graph right after the prefill: next input token = first_token, cache length = lm.cache_len"""
+        self.tok.fill_(int(first_token)); self.pos.fill_(self.lm.cache_len); self.len.fill_(self.lm.cache_len + 1); self.cnt.zero_()
+
+    def capture(self):
+        snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone())
+        s = torch.cuda.Stream(device=self.lm.device)
+        s.wait_stream(torch.cuda.current_stream(self.lm.device))
+        with torch.cuda.stream(s):                          # warm-up outside capture (workspaces, function attributes)
+            self._body()
+        torch.cuda.current_stream(self.lm.device).wait_stream(s)
+        for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
+            t.copy_(v)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = self._body()
+        for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
+            t.copy_(v)
+
+    def run(self, n_tokens: int):
+        """n greedy tokens; returns them as a CPU list (one sync at the end) and advances lm.cache_len"""
+        if self.graph is None:
+            self.capture()
+        for _ in range(n_tokens):
+            self.graph.replay()
+        toks = self.out[:n_tokens].cpu().tolist()
+        self.lm.cache_len += n_tokens
+        return toks
 
 
 class LlavaQwenForCausalLM:
@@ -208,6 +279,7 @@ class LlavaQwenForCausalLM:
         self.device = lm.device
         self.eos_token_id = eos_token_id
         self.training = False
+        self._dg = None
 
     def get_model(self):
         return types.SimpleNamespace(embed_tokens=self.lm.embed_tokens, mm_projector=getattr(self.frame_encoder, "projector", None))
@@ -241,6 +313,13 @@ class LlavaQwenForCausalLM:
         _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
+        if not (do_sample and temperature > 0) and self.eos_token_id is None and max_new_tokens > 1 and kwargs.get("decode_graph", True):
+            first = int(torch.argmax(logits).item())
+            if self._dg is None or self._dg.out.numel() < max_new_tokens:
+                self._dg = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256))
+            self._dg.start(first)
+            rest = self._dg.run(max_new_tokens - 1)
+            return torch.tensor([[first] + rest], dtype=torch.long, device=self.device)
         new = []
         for step in range(max_new_tokens):
             if do_sample and temperature > 0:

@@ -251,26 +251,28 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
     return out
 
 
-def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1):
+def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1,
+              q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None):
     """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused
     QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh]."""
     _require_cuda(q, k, v)
     lib = _lib.load()
     B, Sq = q.shape[0], q.shape[1]
     Skv = k.shape[1]
-    for t in (q, k, v):
+    for t in ((k, v) if q_head_stride else (q, k, v)):
         if t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise StreamChatHipError("attention: tensors must be [B, S, *] with dense batch stride and unit last stride")
     if out is None:
         out = torch.empty((B, Sq, Hq * Dh), dtype=torch.float16, device=q.device)
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
+    ldo = out.stride(1) if out_ld is None else out_ld
     kl = None if kv_len is None else kv_len.to(device=q.device, dtype=torch.int32).contiguous()
     ws = _workspace(B * Hq * Sq * nsplit * (Dh + 2) * 4, q.device) if nsplit > 1 else None
     with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
-        check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), out.stride(1), B, Sq, Skv, Hq, Hkv, Dh,
+        check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), ldo, B, Sq, Skv, Hq, Hkv, Dh,
                                    c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel()),
-                                   stream_ptr(q.device)), "sc_attention_f16")
+                                   q_head_stride, o_head_stride, stream_ptr(q.device)), "sc_attention_f16")
     return out
 
 
@@ -359,7 +361,7 @@ def rope_(x, heads: int, Dh: int, theta: float, pos0: int = 0, positions=None):
     return x
 
 
-def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False):
+def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False, out_row=None):
     """y[N] = w[N,K] @ x[K] (+ bias) (+ residual): batch-1 decode projection (weights streamed once)."""
     _require_cuda(w, x)
     lib = _lib.load()
@@ -368,7 +370,24 @@ def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f
     n_out = N // 2 if epilogue == "swiglu" else N
     if out is None:
         out = torch.empty(n_out, dtype=torch.float32 if out_f32 else torch.float16, device=w.device)
+    from ctypes import c_void_p
     with torch.cuda.device(w.device), _timed("k_gemv", 2.0 * N * K):
-        check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), ptr(out.reshape(-1)), N, K,
-                              EPI[epilogue], 1 if out.dtype == torch.float32 else 0, stream_ptr(w.device)), "sc_gemv_f16")
+        if out_row is not None:                 # `out` is a [rows, ld] buffer; the row index lives on the device
+            check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), c_void_p(out.data_ptr()), N, K,
+                                  EPI[epilogue], 0, ptr(out_row), out.stride(0), stream_ptr(w.device)), "sc_gemv_f16")
+        else:
+            check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), ptr(out.reshape(-1)), N, K,
+                                  EPI[epilogue], 1 if out.dtype == torch.float32 else 0, None, 0, stream_ptr(w.device)), "sc_gemv_f16")
     return out
+
+
+def rope_row_(buf, row_index, heads: int, Dh: int, theta: float):
+    """in-place RoPE on ONE row of `buf` [rows, ld]; the row number (= the token position) is read from the device int32 tensor
+    `row_index` — hipGraph-replayable KV-cache append."""
+    _require_cuda(buf, row_index)
+    lib = _lib.load()
+    from ctypes import c_void_p
+    with torch.cuda.device(buf.device):
+        check(lib.sc_rope_row_f16(c_void_p(buf.data_ptr()), buf.stride(0), ptr(row_index), heads, Dh, c_float(theta), stream_ptr(buf.device)),
+              "sc_rope_row_f16")
+    return buf

@@ -95,3 +95,28 @@ def test_qwen2_7b_width_layers_vs_torch_fp32():
     logits = lm.forward(emb, last_only=False)
     ref = R.qwen2_logits({k: v.float() for k, v in sd.items()}, emb.float(), heads=28, kv_heads=4, layers=2, head_dim=128)
     assert (logits - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
+
+
+def test_decode_graph_matches_eager_greedy():
+    """hipGraph-replayed decode (device-resident position / token) == the eager KV-cache decode == HF greedy ids."""
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    lm = LM.Qwen2Model(sd, cfg, max_seq=128)
+    logits = lm.forward(emb)
+    first = int(logits.argmax())
+    g = LM.DecodeGraph(lm, max_new_tokens=16, nsplit=2)
+    g.start(first)
+    rest = g.run(7)
+    assert [first] + rest == d["greedy"].tolist()
+    assert lm.cache_len == 37 + 7
+    # a second run continues from the advanced cache without re-capturing
+    g.start(rest[-1])
+    more = g.run(3)
+    lm2 = LM.Qwen2Model(sd, cfg, max_seq=128)
+    lg = lm2.forward(emb)
+    seq = []
+    tok = int(lg.argmax())
+    for _ in range(11):
+        seq.append(tok)
+        tok = int(lm2.forward(lm2.embed_tokens(torch.tensor([tok], device="cuda"))).argmax())
+    assert seq == [first] + rest + more
