@@ -128,9 +128,11 @@ int sc_vit_embed_ln_f16(const void* patch, const void* cls, const void* pos, con
 /* Decode-time matrix-vector product y[N] = W[N,K] . x[K] (+ bias) (+ residual): weights streamed once (HBM-bound).
  * epilogue SC_EPI_NONE or SC_EPI_SWIGLU (interleaved gate/up rows, y has N/2 entries).  K % 8 == 0.
  * y_row (optional, device int32[1]): write to row y_row[0] of a [rows, y_ld] fp16 buffer starting at y (KV-cache append at a
- * device-resident position, so a whole decode step can be captured once in a hipGraph and replayed). */
+ * device-resident position, so a whole decode step can be captured once in a hipGraph and replayed).
+ * rms_gamma (optional, fp16 [K]): x is first RMS-normalised as Qwen2RMSNorm does (gamma * fp16(x * rsqrt(mean(x^2) + rms_eps))). */
 int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K,
-                int epilogue, int out_f32, const int32_t* y_row, int y_ld, sc_stream_t stream);
+                int epilogue, int out_f32, const int32_t* y_row, int y_ld, const void* rms_gamma, float rms_eps,
+                sc_stream_t stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim, fp32 statistics; [rows, cols] fp16, cols % 8 == 0,
  * cols <= 4096. */
 int sc_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps, void* y,

@@ -12,7 +12,7 @@ namespace {
 template <bool SWIGLU, bool OUT_F32, int RPW>
 __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
                                               const _Float16* __restrict__ res, void* __restrict__ y_base, int N, int K,
-                                              const int* __restrict__ y_row, int y_ld) {
+                                              const int* __restrict__ y_row, int y_ld, const _Float16* __restrict__ gamma, float eps) {
     // optional dynamic output row (KV-cache append at a device-resident position: keeps a decode step hipGraph-replayable)
     void* y = y_row ? (void*)(reinterpret_cast<_Float16*>(y_base) + (size_t)y_row[0] * (size_t)y_ld) : y_base;
     const int lane = threadIdx.x & 63;
@@ -21,11 +21,30 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
     float acc[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+    // optional fused Qwen2 RMSNorm of x (gamma != NULL): every wave recomputes rsqrt(mean(x^2) + eps) from the L1-resident x and
+    // normalises on the fly with HF's rounding (gamma * fp16(x * rstd)) — removes a latency-bound one-wave kernel per projection
+    float rstd = 1.f;
+    if (gamma) {
+        float ss = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        rstd = rsqrtf(ss / (float)K + eps);
+    }
     const _Float16* wp[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
     for (int k = lane * 8; k < K; k += 512) {
-        const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+        sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+        if (gamma) {
+            const sc_h8 gv = *reinterpret_cast<const sc_h8*>(gamma + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = (_Float16)((float)gv[e] * (float)(_Float16)((float)xv[e] * rstd));
+        }
         sc_h8 wv[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp[r] + (k - lane * 8)));
@@ -66,7 +85,7 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
 }  // namespace
 
 extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K, int epilogue,
-                           int out_f32, const int32_t* y_row, int y_ld, sc_stream_t stream) {
+                           int out_f32, const int32_t* y_row, int y_ld, const void* rms_gamma, float rms_eps, sc_stream_t stream) {
     SC_REQUIRE(W && x && y, "sc_gemv_f16: null pointer argument");
     SC_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "sc_gemv_f16: K must be a positive multiple of 8");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "sc_gemv_f16: W and x must be 16-byte aligned");
@@ -80,11 +99,11 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
     const int rpw = few ? 1 : 4;
     const dim3 grid((unsigned)((N + 4 * rpw - 1) / (4 * rpw))), block(256);
-    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
-    else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
-                        else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld); }
-    else { if (few) hipLaunchKernelGGL((k_gemv<false, false, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld);
-           else hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld); }
+    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+    else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+                        else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
+    else { if (few) hipLaunchKernelGGL((k_gemv<false, false, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+           else hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
     SC_CHECK_LAUNCH("sc_gemv_f16");
     return SC_OK;
 }

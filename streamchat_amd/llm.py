@@ -174,10 +174,9 @@ def _decode_one(self, embeds):
     h = embeds.reshape(1, -1)
     nsplit = max(1, min(128, ((S + 63) // 64) // 2))
     for l, L in enumerate(self.L):
-        x = ops.rmsnorm(h, L["ln1"], c.eps)
-        q = ops.gemv(L["wq"], x, L["bq"]).view(1, dq)
+        q = ops.gemv(L["wq"], h, L["bq"], rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)           # RMSNorm fused into the projections
         kv = self.cache[l][pos0:S]
-        ops.gemv(L["wkv"], x, L["bkv"], out=kv)
+        ops.gemv(L["wkv"], h, L["bkv"], out=kv, rms_gamma=L["ln1"], rms_eps=c.eps)
         ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
         ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
         ck = self.cache[l][:S]
@@ -186,12 +185,10 @@ def _decode_one(self, embeds):
         att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
                             nsplit=nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
         h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
-        x = ops.rmsnorm(h2, L["ln2"], c.eps)
-        m = ops.gemv(L["wgu"], x, None, epilogue="swiglu")
+        m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
         h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
     self.cache_len = S
-    xn = ops.rmsnorm(h, self.norm, c.eps)
-    return ops.gemv(self.lm_head, xn, None, out_f32=True)
+    return ops.gemv(self.lm_head, h, None, out_f32=True, rms_gamma=self.norm, rms_eps=c.eps)
 
 
 Qwen2Model._decode_one = _decode_one
@@ -218,9 +215,8 @@ class DecodeGraph:
         dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
         h = ops.gather_rows(self.tok, lm.embed)
         for l, L in enumerate(lm.L):
-            x = ops.rmsnorm(h, L["ln1"], c.eps)
-            q = ops.gemv(L["wq"], x, L["bq"]).view(1, dq)
-            ops.gemv(L["wkv"], x, L["bkv"], out=lm.cache[l], out_row=self.pos)               # KV row `pos` of the cache
+            q = ops.gemv(L["wq"], h, L["bq"], rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)
+            ops.gemv(L["wkv"], h, L["bkv"], out=lm.cache[l], out_row=self.pos, rms_gamma=L["ln1"], rms_eps=c.eps)   # KV row `pos` of the cache
             ops.rope_(q, c.heads, Dh, c.rope_theta, positions=self.pos)
             ops.rope_row_(lm.cache[l], self.pos, c.kv_heads, Dh, c.rope_theta)
             ck = lm.cache[l]
@@ -228,10 +224,9 @@ class DecodeGraph:
             att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
                                 kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
             h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
-            x = ops.rmsnorm(h2, L["ln2"], c.eps)
-            m = ops.gemv(L["wgu"], x, None, epilogue="swiglu")
+            m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
-        logits = ops.gemv(lm.lm_head, ops.rmsnorm(h, lm.norm, c.eps), None, out_f32=True)
+        logits = ops.gemv(lm.lm_head, h, None, out_f32=True, rms_gamma=lm.norm, rms_eps=c.eps)
         nxt = torch.argmax(logits).reshape(1)
         self.out.index_copy_(0, self.cnt, nxt)
         self.tok.copy_(nxt)

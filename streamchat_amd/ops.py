@@ -361,7 +361,7 @@ def rope_(x, heads: int, Dh: int, theta: float, pos0: int = 0, positions=None):
     return x
 
 
-def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False, out_row=None):
+def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f32: bool = False, out_row=None, rms_gamma=None, rms_eps=1e-6):
     """y[N] = w[N,K] @ x[K] (+ bias) (+ residual): batch-1 decode projection (weights streamed once)."""
     _require_cuda(w, x)
     lib = _lib.load()
@@ -374,10 +374,11 @@ def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f
     with torch.cuda.device(w.device), _timed("k_gemv", 2.0 * N * K):
         if out_row is not None:                 # `out` is a [rows, ld] buffer; the row index lives on the device
             check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), c_void_p(out.data_ptr()), N, K,
-                                  EPI[epilogue], 0, ptr(out_row), out.stride(0), stream_ptr(w.device)), "sc_gemv_f16")
+                                  EPI[epilogue], 0, ptr(out_row), out.stride(0), ptr(rms_gamma), c_float(rms_eps), stream_ptr(w.device)), "sc_gemv_f16")
         else:
             check(lib.sc_gemv_f16(ptr(w), ptr(x), ptr(bias), None if residual is None else ptr(residual.reshape(-1)), ptr(out.reshape(-1)), N, K,
-                                  EPI[epilogue], 1 if out.dtype == torch.float32 else 0, None, 0, stream_ptr(w.device)), "sc_gemv_f16")
+                                  EPI[epilogue], 1 if out.dtype == torch.float32 else 0, None, 0, ptr(rms_gamma), c_float(rms_eps), stream_ptr(w.device)),
+                  "sc_gemv_f16")
     return out
 
 
