@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstreamchat_hip.so")
+LIB_PATH = os.environ.get("SC_LIB") or os.path.join(_HERE, "libstreamchat_hip.so")     # SC_LIB: A/B builds of the kernels
 
 
 class StreamChatHipError(RuntimeError):

@@ -166,6 +166,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
 //   * tile order: XCD-contiguous chunks, inside a chunk groups of GM = 8 tile-rows with the row index fastest.
 // Measured (random operands): 1.09-1.18 PF at K >= 3584, 0.71-0.83 PF at K = 1024 (prologue/epilogue share).
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef SC_GEMM_GM
+#define SC_GEMM_GM 8          // tile-rows per raster group
+#endif
+#ifndef SC_GEMM_SETPRIO
+#define SC_GEMM_SETPRIO 0     // s_setprio(1) around the MFMA clusters
+#endif
+#ifndef SC_GEMM_MPL
+#define SC_GEMM_MPL 1         // MFMAs per interleaved load in the second cluster
+#endif
 constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
 constexpr int HALF2 = BM2 * BK2 * 2;            // 16 KiB per operand per stage
 constexpr int STAGE2 = 2 * HALF2;               // 32 KiB
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     // grouped raster: GM tile-rows per group, tile-row index fastest, so the tiles an XCD runs concurrently form a compact patch
-    constexpr int GM = 8;
+    const int GM = tilesN > 16 ? 4 : SC_GEMM_GM;          // A/B (profiles/r01_run45_gemm_ab.log): wide N prefers 4-row groups (+3.5 % at N = 18944)
     const int tilesM = nwg / tilesN;
     const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
     const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
@@ -273,10 +282,12 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     // reads and the DMA issues of step ks+DIST are INTERLEAVED one-per-MFMA into the second MFMA cluster
     // (sched_group_barrier), so no wave ever sits in a load-issue burst while its SIMD's matrix pipe idles.
     auto kstep = [&](auto sid, int ks, bool steady, sc_h8(&alo)[4], sc_h8(&ahi)[4], sc_h8(&bc)[4], sc_h8(&alo_n)[4], sc_h8(&ahi_n)[4], sc_h8(&bn)[4]) {
+        if (SC_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], alo[i], acc[i][j], 0, 0, 0);
+        if (SC_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         // step ks+1 must have landed for everyone (steps ks+2 .. ks+DIST-1 may stay in flight); slot of step ks-1 is free afterwards
         if (steady) wait_steps(DIST - 2);
         else { const int newest = (ks + DIST - 1) < (nk - 1) ? (ks + DIST - 1) : (nk - 1); wait_steps(newest - (ks + 1)); }
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 #pragma unroll
             for (int i = 0; i < 2 + GW; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x020, 1, SID); }
 #pragma unroll
-            for (int i = 0; i < 12 - (GW - 2); ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, 1, SID); }
+            for (int i = 0; i < (12 - (GW - 2)) / SC_GEMM_MPL; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, SC_GEMM_MPL, SID); }
         }
     };
     int ks = 0;
