@@ -189,7 +189,7 @@ template <int EPI, bool OUT_F32, int WR>
 __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                          const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
                                                          void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
-                                                         int a_grp_stride, int a_grp_off) {
+                                                         int a_grp_stride, int a_grp_off, int GM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = WR * 256;                    // threads
     constexpr int NS = WR == 2 ? 4 : 3;             // ring slots
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     // grouped raster: GM tile-rows per group, tile-row index fastest, so the tiles an XCD runs concurrently form a compact patch
-    const int GM = tilesN > 16 ? 4 : SC_GEMM_GM;          // A/B (profiles/r01_run45_gemm_ab.log): wide N prefers 4-row groups (+3.5 % at N = 18944)
     const int tilesM = nwg / tilesN;
     const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
     const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
@@ -434,6 +433,9 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
     const bool wide_ok = out_f32 || (ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);      // 16-byte epilogue stores
     if (big && wide_ok && N % BN2 == 0 && K % BK2 == 0) {
         // 256x256 tiles; the 128x256 / two-workgroups-per-CU variant is kept for A/B runs (SC_GEMM_KERNEL=2561)
+        static int gmw = -1;                      // raster group for wide N (SC_GEMM_GMW overrides; A/B in profiles/)
+        if (gmw < 0) { const char* e = getenv("SC_GEMM_GMW"); gmw = e ? atoi(e) : 4; }
+        const int gm_sel = (N / BN2) > 16 ? gmw : SC_GEMM_GM;
         const bool half = force == 2561;        // measured: the 256x256 tile wins at every K once the store tail is widened (K-sweep in profiles)
         const int bm = half ? 128 : 256;
         const int tM = (M + bm - 1) / bm, tN = N / BN2;
@@ -446,7 +448,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         if (!attr_done[ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[ai] = true; }
 #define SC_L256(F32, WRV)                                                                                                                 \
         hipLaunchKernelGGL((k_gemm256<EPI, F32, WRV>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
-                           (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off)
+                           (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel)
         if (half) { if (out_f32) SC_L256(true, 1); else SC_L256(false, 1); }
         else { if (out_f32) SC_L256(true, 2); else SC_L256(false, 2); }
 #undef SC_L256
