@@ -18,14 +18,24 @@
 // Block = 4 waves x QB q-blocks of 16 queries; KV tiles of 64 rows double-buffered in LDS via 16-byte
 // global_load_lds; bank-conflict-free XOR swizzles are applied on the per-lane source address and on the reads.
 #include "sc_common.h"
+#include <type_traits>
 
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 typedef short sc_s4 __attribute__((ext_vector_type(4)));
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
 
 constexpr int KVT = 64;   // kv rows per tile
+
+// 16-byte LDS-DMA through a raw buffer resource (base, extent in bytes): lane address = base + voff + soff, destination = the
+// wave-uniform LDS pointer + lane * 16; out-of-range lanes write zeros.  A free function because an opaque
+// __amdgpu_buffer_rsrc_t inside a lambda of the kernel silently drops the kernel's host stub.
+__device__ __forceinline__ void lds_load16(const void* base, int extent, char* lds, unsigned voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
 
 template <int DH, int QB, bool CAUSAL>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
@@ -81,38 +91,44 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     // ---- staging sources ----
     const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
     const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
-    int k_r[GPT], k_s[GPT], v_r[GPT], v_s[GPT];
+    // granule q (16 bytes) of a staged tile -> source row and swizzled 16-byte column slot, for K and for V
+    auto gran = [&](int q, int& kr, int& ks, int& vr, int& vs) {
+        if (DH == 32) {                         // 64-byte rows: 4 granules
+            kr = q >> 2;
+            ks = (q & 3) ^ ((0x78 >> (2 * ((kr >> 2) & 3))) & 3);      // f = {0,2,3,1}[(row>>2)&3]
+            vr = q >> 2;
+            vs = (q & 3) ^ (((vr >> 2) & 1) << 1);
+        } else if (DH == 64) {
+            kr = 2 * (q >> 4) + ((q & 15) >> 3);
+            ks = (q & 7) ^ ((q >> 4) & 7);
+            vr = q >> 3;
+            vs = (q & 7) ^ (((vr >> 1) & 3) << 1);
+        } else {
+            kr = q >> 4;
+            ks = (q & 15) ^ (kr & 15);
+            vr = q >> 4;
+            vs = (q & 15) ^ ((vr & 7) << 1);
+        }
+    };
+    // K/V tiles are fetched with buffer_load ... lds: uniform tile offset in an SGPR (soffset) + a constant per-lane 32-bit
+    // offset (voffset), so the steady state has no per-tile VALU address arithmetic at all, and the hardware bounds check of
+    // the buffer resource returns zeros for rows >= Skv of the ragged last tile (K = 0 scores are masked below; V = 0 is finite).
+    unsigned k_lo[GPT], v_lo[GPT];
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
-        const int q = j * 256 + tid;
-        if (DH == 32) {                         // 64-byte rows: 4 granules
-            k_r[j] = q >> 2;
-            k_s[j] = (q & 3) ^ ((0x78 >> (2 * ((k_r[j] >> 2) & 3))) & 3);      // f = {0,2,3,1}[(row>>2)&3]
-            v_r[j] = q >> 2;
-            v_s[j] = (q & 3) ^ (((v_r[j] >> 2) & 1) << 1);
-        } else if (DH == 64) {
-            k_r[j] = 2 * (q >> 4) + ((q & 15) >> 3);
-            k_s[j] = (q & 7) ^ ((q >> 4) & 7);
-            v_r[j] = q >> 3;
-            v_s[j] = (q & 7) ^ (((v_r[j] >> 1) & 3) << 1);
-        } else {
-            k_r[j] = q >> 4;
-            k_s[j] = (q & 15) ^ (k_r[j] & 15);
-            v_r[j] = q >> 4;
-            v_s[j] = (q & 15) ^ ((v_r[j] & 7) << 1);
-        }
+        int kr, ks, vr, vs;
+        gran(j * 256 + tid, kr, ks, vr, vs);
+        k_lo[j] = ((unsigned)kr * (unsigned)ldk + (unsigned)ks * 8u) * 2u;
+        v_lo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)vs * 8u) * 2u;
     }
+    const int k_bytes = (int)(((unsigned)(Skv - 1) * (unsigned)ldk + DH) * 2u), v_bytes = (int)(((unsigned)(Skv - 1) * (unsigned)ldv + DH) * 2u);
     auto stage = [&](int buf, int t) {
         char* base = smem + buf * STAGE;
-        const int kv0 = t * KVT;
+        const int k_so = t * KVT * ldk * 2, v_so = t * KVT * ldv * 2;
 #pragma unroll
         for (int j = 0; j < GPT; ++j) {
-            int kr = kv0 + k_r[j]; kr = kr < Skv ? kr : Skv - 1;
-            int vr = kv0 + v_r[j]; vr = vr < Skv ? vr : Skv - 1;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kbase + (size_t)kr * (size_t)ldk + k_s[j] * 8),
-                                             (lds_ptr_t)(base + (j * 256 + wave * 64) * 16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (size_t)vr * (size_t)ldv + v_s[j] * 8),
-                                             (lds_ptr_t)(base + TILE + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            lds_load16(kbase, k_bytes, base + (j * 256 + wave * 64) * 16, k_lo[j], k_so);
+            lds_load16(vbase, v_bytes, base + TILE + (j * 256 + wave * 64) * 16, v_lo[j], v_so);
         }
     };
 
@@ -152,82 +168,57 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     const int t_hi = (t_lo + per) < nt ? (t_lo + per) : nt;
     if (t_lo < t_hi) stage(0, t_lo);
     __syncthreads();
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int cur = (t - t_lo) & 1;
-        if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
-        const char* sk = smem + cur * STAGE;
-        const char* sv = sk + TILE;
-
-        // ---- S^T = K . Q^T ----
-        sc_f4 s[4][QB];
+    const sc_f2 sc2 = {scale_log2, scale_log2};
+    // m_run is the REFERENCE max of a row in the scaled log2 domain: p = 2^(s*scale - m_run); O and l are relative to the same
+    // reference, so the final O / l does not depend on it.  Two tile bodies share the loop:
+    //   SLOW (general): masks, moves the reference to the true running max and rescales O (exact online softmax step);
+    //   FAST: no mask arithmetic, no O rescale - valid while every kv of the tile is visible to every query of the wave and no
+    //         row max outgrows its reference by more than 2^8 (p <= 256, far inside fp16).  After the first tile or two that is
+    //         nearly every tile of a long sequence.  The fast body is a loop of its own in which O is only ever touched by the
+    //         accumulating MFMAs; a rescale branch inside one shared body made the compiler keep two copies of O (64 extra
+    //         VGPRs and 32..66 register moves per tile).  A fast tile that finds a row needing a new reference leaves the loop
+    //         BEFORE touching O or l and is redone by the slow body (its K/V tile is still in LDS, its prefetch already issued).
+    auto s_phase = [&](const char* sk, sc_f4 (&s)[4][QB]) {
+        constexpr int NKF = 4 * DS;
+        sc_h8 kfr[2];
+        kfr[0] = *reinterpret_cast<const sc_h8*>(sk + k_off[0]);
 #pragma unroll
-        for (int kvb = 0; kvb < 4; ++kvb) {
+        for (int i = 0; i < NKF; ++i) {
+            const int kvb = i / DS, ds = i % DS;
+            if (i + 1 < NKF) kfr[(i + 1) & 1] = *reinterpret_cast<const sc_h8*>(sk + ((i + 1) / DS) * KBLK + k_off[(i + 1) % DS]);
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) s[kvb][qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                const sc_h8 kf = *reinterpret_cast<const sc_h8*>(sk + kvb * KBLK + k_off[ds]);
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ds], s[kvb][qb], 0, 0, 0);
+            for (int qb = 0; qb < QB; ++qb) {
+                const sc_f4 acc = ds == 0 ? sc_f4{0.f, 0.f, 0.f, 0.f} : s[kvb][qb];
+                s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[i & 1], qf[qb][ds], acc, 0, 0, 0);
             }
         }
-
-        // ---- online softmax (per lane = per query column) ----
-        // m_run is kept in the scaled log2 domain; scores are scaled inside the exp2 argument with one FMA.
-        // Interior tiles (every kv visible to every query of this wave) take a mask-free path.
-        sc_h8 pf[QB][2];
-        const int kv_t0 = t * KVT + g * 4;
-        bool need_mask = (t * KVT + KVT > kv_valid);
-        if (CAUSAL) need_mask = need_mask || (t * KVT + KVT - 1 > qw0 + coff);      // wave-uniform
+    };
+    auto row_max = [&](const sc_f4 (&s)[4][QB], int qb) {
+        float tmax = -INFINITY;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float tmax = -INFINITY;
-            if (need_mask) {
-                const int qpos = qw0 + qb * 16 + rl + coff;
+        for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
-                for (int kvb = 0; kvb < 4; ++kvb)
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        return tmax * scale_log2;                                                    // scale > 0: max commutes with scaling
+    };
+    auto p_phase = [&](const sc_f4 (&s)[4][QB], int qb, float m_use, sc_h8 (&pf)[QB][2]) {
+        const sc_f2 m2 = {m_use, m_use};
+        sc_f2 ps2 = {0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kv = kv_t0 + kvb * 16 + r;
-                        const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
-                        const float x = dead ? -INFINITY : s[kvb][qb][r];
-                        s[kvb][qb][r] = x;
-                        tmax = fmaxf(tmax, x);
-                    }
-            } else {
+        for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
-                for (int kvb = 0; kvb < 4; ++kvb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
+            for (int r = 0; r < 4; r += 2) {
+                const sc_f2 x = sc_f2{s[kvb][qb][r], s[kvb][qb][r + 1]} * sc2 - m2;
+                const sc_f2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                ps2 += p;
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p[0];
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p[1];
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qb], tmax * scale_log2);                 // scale > 0: max commutes with scaling
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int kvb = 0; kvb < 4; ++kvb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, -m_use));
-                    psum += p;
-                    pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p;
-                }
-            // exact skip: if no query of this wave raised its running max, alpha == 1 for every lane
-            if (__any(m_new != m_run[qb])) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
-                l_run[qb] = l_run[qb] * alpha + psum;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    o[db][qb][0] *= alpha; o[db][qb][1] *= alpha; o[db][qb][2] *= alpha; o[db][qb][3] *= alpha;
-                }
-                m_run[qb] = m_new;
-            } else {
-                l_run[qb] += psum;
-            }
-        }
-
-        // ---- O^T += V^T . P^T ----
+        l_run[qb] += ps2[0] + ps2[1];
+    };
+    auto pv_phase = [&](const char* sv, const sc_h8 (&pf)[QB][2]) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -242,7 +233,68 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][c], o[db][qb], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    auto masked = [&](int t) {
+        bool m = (t * KVT + KVT > kv_valid);
+        if (CAUSAL) m = m || (t * KVT + KVT - 1 > qw0 + coff);                        // wave-uniform
+        return m;
+    };
+
+    int t = t_lo;
+    bool staged = false;                       // tile t + 1 already requested by a fast iteration that bailed out
+    while (t < t_hi) {
+        // ---------------- SLOW tile ----------------
+        {
+            const int cur = (t - t_lo) & 1;
+            if (!staged && t + 1 < t_hi) stage(cur ^ 1, t + 1);
+            staged = false;
+            const char* sk = smem + cur * STAGE;
+            sc_f4 s[4][QB];
+            s_phase(sk, s);
+            sc_h8 pf[QB][2];
+            const int kv_t0 = t * KVT + g * 4;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int qpos = qw0 + qb * 16 + rl + coff;
+#pragma unroll
+                for (int kvb = 0; kvb < 4; ++kvb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kv = kv_t0 + kvb * 16 + r;
+                        const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                        s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
+                    }
+                const float m_new = fmaxf(m_run[qb], row_max(s, qb));
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);       // 1 when the reference did not move, 0 at the start
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
+                p_phase(s, qb, m_use, pf);
+            }
+            pv_phase(sk + TILE, pf);
+            __syncthreads();
+            ++t;
+        }
+        // ---------------- FAST tiles ----------------
+        while (t < t_hi && !masked(t)) {
+            const int cur = (t - t_lo) & 1;
+            if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
+            const char* sk = smem + cur * STAGE;
+            sc_f4 s[4][QB];
+            s_phase(sk, s);
+            bool need = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) need = need || (row_max(s, qb) > m_run[qb] + 8.0f);
+            if (__any(need)) { staged = true; break; }
+            sc_h8 pf[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) p_phase(s, qb, m_run[qb], pf);
+            pv_phase(sk + TILE, pf);
+            __syncthreads();
+            ++t;
+        }
     }
 
     // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----
