@@ -199,8 +199,12 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        // max over the 4 lane groups holding this query column: two VALU row swaps (v_permlane16_swap / v_permlane32_swap with the
+        // value as both operands give x and its xor-16 / xor-32 partner) instead of two ~100-cycle ds_bpermute round trips
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
         return tmax * scale_log2;                                                    // scale > 0: max commutes with scaling
     };
     auto p_phase = [&](const sc_f4 (&s)[4][QB], int qb, float m_use, sc_h8 (&pf)[QB][2]) {
