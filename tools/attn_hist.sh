@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-basic-block instruction histogram of the main loop of k_attn<128,2,causal> (run tools/attn_regs.sh first)
-awk '/^_ZN12_GLOBAL__N_16k_attnILi128ELi2ELb1E/,/^\.Lfunc_end/' /tmp/attn2.s > /tmp/b.s
+awk "/^${FN:-_ZN12_GLOBAL__N_16k_attnILi128ELi2ELb1E}/,/^\\.Lfunc_end/" /tmp/attn2.s > /tmp/b.s
 python3 - <<'PY'
 import re, collections
 L=[l.rstrip() for l in open('/tmp/b.s')]
