@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         k_lo[j] = ((unsigned)kr * (unsigned)ldk + (unsigned)ks * 8u) * 2u;
         v_lo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)vs * 8u) * 2u;
     }
-    const int k_bytes = (int)(((unsigned)(Skv - 1) * (unsigned)ldk + DH) * 2u), v_bytes = (int)(((unsigned)(Skv - 1) * (unsigned)ldv + DH) * 2u);
+    // extent = the VALID rows only: rows in [kv_valid, Skv) of a cache hold whatever the allocator left there, and a NaN in V
+    // would survive the multiplication by p = 0 in the P.V MFMA; beyond the extent the DMA writes zeros instead
+    const int k_bytes = kv_valid > 0 ? (int)(((unsigned)(kv_valid - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_bytes = kv_valid > 0 ? (int)(((unsigned)(kv_valid - 1) * (unsigned)ldv + DH) * 2u) : 0;
     auto stage = [&](int buf, int t) {
         char* base = smem + buf * STAGE;
         const int k_so = t * KVT * ldk * 2, v_so = t * KVT * ldv * 2;

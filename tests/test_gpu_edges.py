@@ -83,3 +83,17 @@ def test_preprocess_rejects_bad_input():
         ops.preprocess_u8(torch.zeros(1, 4, 4, 3).cuda())                          # not uint8
     with pytest.raises(StreamChatHipError):
         ops.preprocess_patchify_u8(torch.zeros(1, 30, 28, 3, dtype=torch.uint8).cuda(), 14, 640)   # 30 % 14 != 0
+
+
+def test_attention_ignores_garbage_beyond_kv_len():
+    """Rows of a KV cache past kv_len hold allocator garbage (possibly NaN / Inf): they must not reach the output."""
+    torch.manual_seed(3)
+    q = torch.randn(1, 5, 2 * 128).cuda().half()
+    kv = torch.randn(1, 200, 2 * 128).cuda().half()
+    k, v = kv.clone(), kv.flip(1).contiguous()
+    kv_len = torch.tensor([70], device="cuda", dtype=torch.int32)
+    ref = ops.attention(q, k[0, :70].clone()[None], v[0, :70].clone()[None], 2, 2, 128, 0.09, False)
+    k[:, 70:] = float("nan"); v[:, 70:] = float("inf"); v[:, 100:] = float("nan")
+    out = ops.attention(q, k, v, 2, 2, 128, 0.09, False, kv_len)
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out.float(), ref.float(), rtol=1e-3, atol=1e-3)
