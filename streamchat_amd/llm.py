@@ -53,8 +53,12 @@ def _h(t, device):
 class Qwen2Model:
     """Decoder stack + lm_head on the HIP kernels, with a contiguous per-layer KV cache [max_seq, 2*Hkv*Dh] (K | V)."""
 
-    def __init__(self, state_dict, cfg: Qwen2ConfigLite, device="cuda", max_seq=65536, consume=False):
+    def __init__(self, state_dict, cfg: Qwen2ConfigLite, device="cuda", max_seq=65536, consume=False, trim_last_layer=False):
         self.cfg, self.device, self.max_seq = cfg, torch.device(device), max_seq
+        # opt-in: in a last_only prefill run the last layer's query / attention / MLP for the final row only (K/V still for every
+        # row).  Same logits and same cache, 1/layers fewer flops; OFF by default so that the default path (and bench.py) does
+        # exactly the work the reference's HF forward does.
+        self.trim_last_layer = trim_last_layer
         H, I, Dh = cfg.hidden, cfg.intermediate, cfg.head_dim
         if H % 128 or I % 128 or (cfg.heads * Dh) % 128 or (2 * cfg.kv_heads * Dh) % 128 or cfg.vocab % 128 or Dh not in (32, 64, 128):
             raise ValueError("HIP Qwen2 path needs 128-multiple widths and head_dim in {32, 64, 128}")
@@ -116,10 +120,26 @@ class Qwen2Model:
         h.copy_(embeds)
         h2 = B["h2"][:n]
         S = pos0 + n
+        tail = None
         for l, L in enumerate(self.L):
             x = ops.rmsnorm(h, L["ln1"], c.eps, out=B["x"][:n])
-            q = ops.gemm(x, L["wq"], L["bq"], out=B["q"][:n])
             kv = ops.gemm(x, L["wkv"], L["bkv"], out=self.cache[l][pos0:S])
+            if self.trim_last_layer and last_only and l == len(self.L) - 1:
+                # Only the last position's logits are wanted: in the LAST layer every row still contributes its K/V (cache), but
+                # the query, attention, output projection and MLP are needed for the final row alone (1/layers of the prefill
+                # flops saved; HF computes all rows and slices the logits afterwards - the returned row is the same).
+                ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
+                ql = ops.gemm(x[n - 1:n], L["wq"], L["bq"])
+                ops.rope_(ql, c.heads, Dh, c.rope_theta, S - 1)
+                ck = self.cache[l][:S]
+                nsplit = max(1, min(128, ((S + 63) // 64) // 2))
+                al = ops.attention(ql.unsqueeze(0), ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.heads, c.kv_heads, Dh, Dh ** -0.5,
+                                   causal=True, nsplit=nsplit).squeeze(0)
+                hl = ops.gemm(al, L["wo"], None, residual=h[n - 1:n])
+                ml = ops.gemm(ops.rmsnorm(hl, L["ln2"], c.eps), L["wgu"], None, epilogue="swiglu")
+                tail = ops.gemm(ml, L["wd"], None, residual=hl)
+                break
+            q = ops.gemm(x, L["wq"], L["bq"], out=B["q"][:n])
             ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
             ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)                       # K occupies columns [0, dkv) of the cache row
             ck = self.cache[l][:S]
@@ -130,7 +150,8 @@ class Qwen2Model:
             m = ops.gemm(x, L["wgu"], None, epilogue="swiglu", out=B["m"][:n])
             ops.gemm(m, L["wd"], None, residual=h2, out=h)
         self.cache_len = S
-        tail = h[n - 1:n] if last_only else h
+        if tail is None:
+            tail = h[n - 1:n] if last_only else h
         xn = ops.rmsnorm(tail, self.norm, c.eps)
         logits = ops.gemm(xn, self.lm_head, None, out_f32=True)
         return logits[0] if last_only else logits

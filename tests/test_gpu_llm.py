@@ -120,3 +120,15 @@ def test_decode_graph_matches_eager_greedy():
         seq.append(tok)
         tok = int(lm2.forward(lm2.embed_tokens(torch.tensor([tok], device="cuda"))).argmax())
     assert seq == [first] + rest + more
+
+
+def test_trimmed_last_layer_gives_same_logits_and_cache():
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    a = LM.Qwen2Model(sd, cfg, max_seq=64)
+    b = LM.Qwen2Model(sd, cfg, max_seq=64, trim_last_layer=True)
+    la, lb = a.forward(emb), b.forward(emb)
+    torch.testing.assert_close(lb, la, rtol=2e-3, atol=2e-3)
+    assert int(la.argmax()) == int(lb.argmax())
+    for ca, cb in zip(a.cache, b.cache):
+        assert torch.equal(ca[:37], cb[:37])                                    # K/V of every layer and row are still produced
