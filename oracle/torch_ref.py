@@ -31,6 +31,20 @@ def _mha(x, sd, pre, heads, mask=None, causal=False):
     return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_u8(u8_nhwc, mean=CLIP_MEAN, std=CLIP_STD):
+    """reference utiles.py:71-87 -> HF CLIPImageProcessor.preprocess on frames that are already 336x336 (resize and centre-crop
+    are identities): transformers image_transforms.rescale (float64 product, cast to float32) then normalize (float32), CHW.
+    numpy uint8 [N,H,W,3] -> float32 [N,3,H,W].  Pinned by tests/golden/preprocess.npz (the processor's own output)."""
+    import numpy as np
+    x = (np.asarray(u8_nhwc).astype(np.float64) * (1 / 255)).astype(np.float32)
+    x = (x - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
 def clip_vision_hidden(sd, pixel_values, *, heads, patch, layers_run, eps=1e-5, prefix="vision_model."):
     """hidden state after `layers_run` encoder layers (HF hidden_states[layers_run]); [N, 1+P, D] fp32.
     HF CLIPVisionTransformer: patch Conv2d(no bias) -> [cls | patches] + position embedding -> pre_layrnorm ->

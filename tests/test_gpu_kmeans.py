@@ -114,3 +114,25 @@ def test_tree_trace_on_gpu():
         tree = U.fast_building_memory_tree_summarize_token(km, K, interval, summ, torch.zeros(1, 3, dtype=torch.long), tok, chunked, tree)
         got = describe(tree)
         assert [(n["depth"], n["shape"], len(n["children"])) for n in got] == [(n["depth"], n["shape"], len(n["children"])) for n in upd["top"]]
+
+
+@pytest.mark.parametrize("T,K,centres_n,max_iter", [(64, 8, 6, 10), (400, 5, 5, 3)], ids=["C1_T64_K8", "merge_T400_K5"])
+def test_kmeans_full_size_bit_exact_vs_oracle(T, K, centres_n, max_iter):
+    """FULL-size k-means (D = 576*3584, fp16 storage): BASELINE C1 (T = 64 frames, K = 8, 0.26 GB) and the shipped memory-merge
+    shape (T = 400, K = 5, 1.65 GB; max_iter = 3 keeps the scalar oracle at a few seconds).  Labels, centroids, weights and the
+    iteration count are bit-identical to the C oracle."""
+    D = 576 * 3584
+    g = torch.Generator(device="cuda").manual_seed(T)
+    centres = torch.randn(centres_n, D, device="cuda", generator=g)
+    which = torch.randint(0, centres_n, (T,), device="cuda", generator=g)
+    X = torch.empty(T, D, device="cuda", dtype=torch.float16)
+    for i in range(0, T, 50):                                                     # build in slabs: no 3 GB fp32 temporary
+        X[i:i + 50] = (centres[which[i:i + 50]] + 0.5 * torch.randn(min(50, T - i), D, device="cuda", generator=g)).half()
+    init = torch.randperm(T, generator=torch.Generator().manual_seed(0))[:K].to(torch.int32)
+    reseed = torch.arange(max_iter * K, dtype=torch.int32) % T
+    C, labels, wsum, info = ops.kmeans_fit(X, K, init, reseed, max_iter=max_iter)
+    ref = oracle.kmeans_fit(X.cpu().numpy(), K, init.numpy(), reseed.numpy(), max_iter=max_iter)
+    assert np.array_equal(labels.cpu().numpy(), ref["labels"])
+    assert int(info[0]) == ref["iters"]
+    assert np.array_equal(wsum.cpu().numpy(), ref["wsum"])
+    assert np.array_equal(C.cpu().numpy(), ref["centroids"])

@@ -27,6 +27,17 @@ def test_preprocess_bit_exact(n, h, w):
     assert np.array_equal(out.cpu().numpy().view(np.uint16), ref_preprocess(u8).view(np.uint16))
 
 
+def test_preprocess_matches_hf_processor_golden():
+    """G1: bit-exact against the output of HF CLIPImageProcessor (what reference utiles.py:71-87 calls) on 4 seeded frames."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess.npz"))
+    u8 = np.random.default_rng(int(d["seed"])).integers(0, 256, tuple(d["shape"]), dtype=np.uint8)
+    import zlib
+    assert zlib.crc32(u8[0].tobytes()) == int(d["first_frame_crc"])          # the seeded generator reproduced the fixture's input
+    out = ops.preprocess_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    assert np.array_equal(out[:, :, ::8, ::8].view(np.uint16), d["sub"].view(np.uint16))
+    assert out.astype(np.float64).sum() == float(d["sum64"])
+
+
 def test_preprocess_patchify_matches_unfold():
     n, h, w, P, ld = 2, 56, 42, 14, 640
     u8 = np.random.default_rng(7).integers(0, 256, (n, h, w, 3), dtype=np.uint8)

@@ -61,3 +61,14 @@ def test_qwen2_vs_hf():
         toks.append(t)
         emb = torch.cat([emb, sd["model.embed_tokens.weight"][t][None]])
     assert toks == d["greedy"].tolist()
+
+
+def test_preprocess_restatement_matches_hf_processor_golden():
+    """G1: oracle.torch_ref.preprocess_u8 == HF CLIPImageProcessor output (fixture made by tools/make_golden_hf.py)."""
+    import zlib
+    d = np.load(os.path.join(G, "preprocess.npz"))
+    u8 = np.random.default_rng(int(d["seed"])).integers(0, 256, tuple(d["shape"]), dtype=np.uint8)
+    assert zlib.crc32(u8[0].tobytes()) == int(d["first_frame_crc"])
+    h = R.preprocess_u8(u8).astype(np.float16)
+    assert np.array_equal(h[:, :, ::8, ::8].view(np.uint16), d["sub"].view(np.uint16))
+    assert h.astype(np.float64).sum() == float(d["sum64"])

@@ -7,6 +7,7 @@ saved, so oracle/torch_ref.py (and through it the HIP kernels) are pinned to the
 sites reference clip_encoder.py:76 (output_hidden_states, select layer -2, drop CLS), multimodal_projector/
 builder.py:41-48, utiles.py:707 (BertModel CLS) and llava_qwen.py:155."""
 import os
+import zlib
 import sys
 
 import numpy as np
@@ -91,6 +92,23 @@ def gen_qwen2():
     np.savez_compressed(os.path.join(OUT, "qwen2_tiny.npz"), **d)
 
 
+
+def gen_preprocess():
+    """G1: the reference's `process_images` (utiles.py:71-87) hands every frame to HF `CLIPImageProcessor.preprocess`; on 336x336
+    frames resize / centre-crop are identities and what is left is rescale (x * 1/255) + normalise.  The fixture keeps the seed of
+    the 4 uint8 frames, an 8x8-strided fp16 subsample of the processor's output and the float64 sum of its fp16 rounding."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(do_resize=True, size={"shortest_edge": 336}, do_center_crop=True, crop_size={"height": 336, "width": 336},
+                              do_rescale=True, do_normalize=True, image_mean=[0.48145466, 0.4578275, 0.40821073],
+                              image_std=[0.26862954, 0.26130258, 0.27577711], do_convert_rgb=True)
+    frames = np.random.default_rng(1234).integers(0, 256, size=(4, 336, 336, 3), dtype=np.uint8)
+    out = proc.preprocess([Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"].numpy()
+    h = out.astype(np.float16)
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), seed=np.int64(1234), shape=np.array(frames.shape), sub=h[:, :, ::8, ::8],
+                        sum64=np.float64(h.astype(np.float64).sum()), first_frame_crc=np.int64(zlib.crc32(frames[0].tobytes())))
+
+
 if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("authoring container only")
@@ -98,4 +116,5 @@ if __name__ == "__main__":
     gen_clip()
     gen_bert()
     gen_qwen2()
-    print("transformers", transformers.__version__, "-> clip_tiny.npz bert_tiny.npz qwen2_tiny.npz")
+    gen_preprocess()
+    print("transformers", transformers.__version__, "-> clip_tiny.npz bert_tiny.npz qwen2_tiny.npz preprocess.npz")
