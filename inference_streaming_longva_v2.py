@@ -60,6 +60,8 @@ def parse_args(argv=None):
     p.add_argument("--embedding_model_id", type=str, default=None, help="mxbai-colbert-large-v1 checkpoint (reference :703)")
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
     p.add_argument("--max_new_tokens", type=int, default=256)
+    p.add_argument("--memory_tree_dir", type=str, default=None,
+                   help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
     return p.parse_args(argv)
 
 
@@ -184,6 +186,10 @@ def run_inference(args):
             memory = save_local_memory(memory, [[question, output]], user_name, args)
             _, _, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)
             memory_config["user_memory_index"] = user_memory_index
+            if args.memory_tree_dir and long_memory_tree is not None:
+                from streamchat_amd.persistence import save_memory_tree
+                save_memory_tree(long_memory_tree, os.path.join(args.memory_tree_dir, f"video_{inference_count}"), short_memory_buffer,
+                                 extra=dict(time=questions["time"], question=question))
         inference_count += 1
 
 

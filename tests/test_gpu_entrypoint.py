@@ -13,7 +13,7 @@ def test_run_inference_synthetic_tiny(tmp_path):
     args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(tmp_path / "mem"), "--save_file",
                          str(tmp_path / "out.json"), "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "1",
                          "--tiny", "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3",
-                         "--max_new_tokens", "4", "--multi_modal_memory"])
+                         "--max_new_tokens", "4", "--multi_modal_memory", "--memory_tree_dir", str(tmp_path / "trees")])
     E.run_inference(args)
     out = json.load(open(tmp_path / "out.json"))
     assert len(out) == 2 and all(set(r) == {"time", "question", "label", "predict", "class", "process_time"} for r in out)
@@ -21,6 +21,12 @@ def test_run_inference_synthetic_tiny(tmp_path):
     turns = [t for day in mem["User"]["history"].values() for t in day]
     assert [t["query"] for t in turns] == [r["question"] for r in out]
     assert os.path.exists(tmp_path / "mem" / "memory_index" / "User_index" / "index.npy")      # dialogue index rebuilt per round
+    # the visual memory tree of the session was persisted and loads back onto the device
+    from streamchat_amd.persistence import load_memory_tree
+    from streamchat_amd import utiles as U
+    nodes, short, extra = load_memory_tree(str(tmp_path / "trees" / "video_0"))
+    assert len(nodes) > 0 and all(n.centroids.is_cuda for n in nodes) and len(short) > 0 and extra["question"] == out[-1]["question"]
+    assert sum(U.count_nodes_by_depth(nodes).values()) >= len(nodes)
 
 
 def test_parse_args_has_reference_flags():
