@@ -72,3 +72,18 @@ def test_encode_images_vit_l_vs_torch_fp32():
     # frames are independent: encoding frame 1 alone gives the same rows as inside the batch
     single = enc.encode_frames_u8(u8[1:2])
     assert torch.equal(single[0], out[1])
+
+
+def test_async_ingest_equals_synchronous_encode():
+    """host frames -> pinned staging -> copy stream -> encode (streamchat_amd/ingest.py) gives the same bank, bit for bit, as one
+    synchronous encode_frames_u8 with the same micro-batch, including a ragged tail and more micro-batches than staging slots."""
+    from streamchat_amd.ingest import AsyncFrameIngest
+    d, sd, sp, cfg = _tiny()
+    enc = V.FrameEncoder(V.CLIPVisionTower(sd, cfg), V.MMProjector(sp), micro_batch=4)
+    frames = np.random.default_rng(5).integers(0, 256, (19, 56, 56, 3), dtype=np.uint8)
+    ref = enc.encode_frames_u8(torch.from_numpy(frames).cuda())
+    bank = torch.zeros(19, 16, 256, dtype=torch.float16, device="cuda")
+    ing = AsyncFrameIngest(enc.encode_frames_u8, (56, 56, 3), micro_batch=4, depth=2)
+    assert ing.run(iter(frames), bank) == 19 and ing.stats["micro_batches"] == 5
+    torch.cuda.synchronize()
+    assert torch.equal(bank, ref)
