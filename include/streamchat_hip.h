@@ -171,11 +171,14 @@ int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L
  *   processed by separate workgroups and merged; needs ws of B*Hq*Sq*nsplit*(Dh+2)*4 bytes.  nsplit = 1: ws may be NULL.
  *   q_head_stride / o_head_stride (elements; 0 = Dh): distance between consecutive heads inside a q / out row.  With
  *   ldq = Dh and q_head_stride = G*Dh the G query heads of a GQA group become G query ROWS of one KV head without any copy
- *   (decode: every K/V byte is then read once for the whole group). */
+ *   (decode: every K/V byte is then read once for the whole group).
+ *   q_batch_stride / o_batch_stride (elements; 0 = Sq*ldq / Sq*ldo): distance between consecutive batch rows of q / out, so the
+ *   head-packed addressing also works for B > 1 (batched decode: q is [B, Hq*Dh] and its batch stride is Hq*Dh, not G*Dh).
+ *   k / v batch rows are Skv*ldk / Skv*ldv apart. */
 int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                      int ldo, int B, int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal,
                      const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
-                     int o_head_stride, sc_stream_t stream);
+                     int o_head_stride, int64_t q_batch_stride, int64_t o_batch_stride, sc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,7 @@ template <int DH, int QB, bool CAUSAL>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
                                               int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
-                                              float* __restrict__ part, int nsplit, int B, int q_hs, int o_hs) {
+                                              float* __restrict__ part, int nsplit, int B, int q_hs, int o_hs, long q_bs, long o_bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = KVT * DH * 2;            // bytes per K (or V) tile
     constexpr int STAGE = 2 * TILE;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     for (int qb = 0; qb < QB; ++qb) {
         int qr = qw0 + qb * 16 + rl;
         qr = qr < Sq ? qr : Sq - 1;
-        const _Float16* qp = Q + ((size_t)b * Sq + qr) * (size_t)ldq + h * q_hs + g * 8;
+        const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
 #pragma unroll
         for (int ds = 0; ds < DS; ++ds) qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
     }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 if (g == 0) { pp[DH] = m_run[qb]; pp[DH + 1] = l; }
             }
         } else if (qr < Sq) {
-            _Float16* op = O + ((size_t)b * Sq + qr) * (size_t)ldo + h * o_hs + g * 4;
+            _Float16* op = O + (size_t)b * (size_t)o_bs + (size_t)qr * (size_t)ldo + h * o_hs + g * 4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const sc_h4 v = {(_Float16)(o[db][qb][0] * inv), (_Float16)(o[db][qb][1] * inv), (_Float16)(o[db][qb][2] * inv),
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 // (batch, head, query): the split weights are computed once by the first wave (one lane per split), then every thread owns one
 // output dimension and sums the weighted partials with independent loads.
 template <int DH>
-__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit, int o_hs) {
+__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit, int o_hs, long o_bs) {
     __shared__ float wgt[1024];
     __shared__ float inv_den;
     const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
@@ -369,12 +369,12 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
         for (int u = 0; u < 8; ++u) num += v[u] * wgt[i + u];
     }
     for (; i < nsplit; ++i) num += pp[i * (DH + 2) + d] * wgt[i];
-    O[((size_t)b * Sq + q) * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
+    O[(size_t)b * (size_t)o_bs + (size_t)q * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
 }
 
 template <int DH, int QB>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
-                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, hipStream_t s) {
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s) {
     const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16), G = Hq / Hkv;
     const int npairs = nqb * Hkv * B;
     const dim3 grid((unsigned)(((npairs + 7) / 8) * 8 * G * nsplit)), block(256);
@@ -382,11 +382,11 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
     const float sl2 = scale * 1.4426950408889634f;
     if (causal)
         hipLaunchKernelGGL((k_attn<DH, QB, true>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
     else
         hipLaunchKernelGGL((k_attn<DH, QB, false>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs);
-    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs);
+                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
+    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
     SC_CHECK_LAUNCH("sc_attention_f16");
     return SC_OK;
 }
@@ -395,7 +395,8 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
 
 extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
                                 int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
-                                int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, sc_stream_t stream) {
+                                int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, int64_t q_batch_stride,
+                                int64_t o_batch_stride, sc_stream_t stream) {
     SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
     SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
     SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
@@ -413,7 +414,9 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     }
     const int qhs = q_head_stride > 0 ? q_head_stride : Dh, ohs = o_head_stride > 0 ? o_head_stride : Dh;
     SC_REQUIRE(qhs % 8 == 0 && ohs % 4 == 0, "sc_attention_f16: head strides must be multiples of 8 (q) / 4 (out)");
-    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
-    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
-    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, s);
+    const long qbs = q_batch_stride > 0 ? (long)q_batch_stride : (long)Sq * ldq, obs = o_batch_stride > 0 ? (long)o_batch_stride : (long)Sq * ldo;
+    SC_REQUIRE(qbs % 8 == 0 && obs % 4 == 0, "sc_attention_f16: batch strides must be multiples of 8 (q) / 4 (out)");
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
 }

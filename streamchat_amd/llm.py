@@ -284,6 +284,123 @@ class DecodeGraph:
         return toks
 
 
+class BatchDecoder:
+    """Decode B sequences together (the reference captions every 40-frame chunk with its own 7B generate at batch 1 and
+    without a KV cache, utiles.py:539-559).  Each sequence is prefilled on its own (prefill is compute-bound, batching buys nothing)
+    into slice b of ONE per-layer cache [B, cap, 2*dkv]; decode then advances all B sequences per step: the projections are GEMMs
+    with M = B, so the 15 GB of weights stream once per step instead of once per sequence, the new K/V rows are scattered with one
+    index_copy per layer, and attention is ONE launch per layer over the batch (per-sequence kv_len, split-KV)."""
+
+    def __init__(self, lm, prompts, max_new_tokens):
+        """prompts: list of [n_b, H] fp16 embeddings (image rows already spliced)."""
+        c = lm.cfg
+        self.lm, self.B = lm, len(prompts)
+        self.cap = max(int(e.shape[0]) for e in prompts) + max_new_tokens
+        dev = lm.device
+        self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
+        self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        first_logits = []
+        saved = (lm.cache, lm.cache_len, lm.max_seq)
+        try:
+            for b, e in enumerate(prompts):
+                lm.cache, lm.cache_len, lm.max_seq = [cl[b] for cl in self.cache], 0, self.cap
+                first_logits.append(lm.forward(e.to(dev)))
+                self.len[b] = lm.cache_len
+        finally:
+            lm.cache, lm.cache_len, lm.max_seq = saved
+        self.logits = torch.stack(first_logits)                                  # [B, vocab] fp32
+
+    def step(self, tokens):
+        """tokens [B] int32 (device) -> logits [B, vocab] fp32 for the next position of every sequence.  Everything that changes from
+        step to step (tokens, lengths, cache rows) lives in device tensors, so the step is hipGraph-capturable."""
+        lm, c, B = self.lm, self.lm.cfg, self.B
+        dq, dkv, Dh = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim
+        h = ops.gather_rows(tokens, lm.embed)
+        rows = self._row0 + self.len.to(torch.int64)
+        kvlen = self.len + 1
+        for l, L in enumerate(lm.L):
+            x = ops.rmsnorm(h, L["ln1"], c.eps)
+            q = ops.gemm(x, L["wq"], L["bq"])
+            kv = ops.gemm(x, L["wkv"], L["bkv"])
+            ops.rope_(q, c.heads, Dh, c.rope_theta, positions=self.len)
+            ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, positions=self.len)     # K = columns [0, dkv)
+            ck = self.cache[l]
+            ck.view(B * self.cap, -1).index_copy_(0, rows, kv)
+            # the G query heads of a KV group as G query ROWS of that KV head (addressing only; q batch stride = dq)
+            G = c.heads // c.kv_heads
+            att = ops.attention(q.as_strided((B, G, Dh), (dq, Dh, 1)), ck[:, :, :dkv], ck[:, :, dkv:], c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,
+                                causal=False, kv_len=kvlen, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(B, dq)
+            h2 = ops.gemm(att, L["wo"], None, residual=h)
+            m = ops.gemm(ops.rmsnorm(h2, L["ln2"], c.eps), L["wgu"], None, epilogue="swiglu")
+            h = ops.gemm(m, L["wd"], None, residual=h2)
+        self.len += 1
+        return ops.gemm(ops.rmsnorm(h, lm.norm, c.eps), lm.lm_head, None, out_f32=True)
+
+    def _pick(self, logits, do_sample, temperature, generator=None):
+        if do_sample and temperature > 0:
+            return torch.multinomial(torch.softmax(logits / temperature, dim=-1), 1, generator=generator).view(-1)
+        return torch.argmax(logits, dim=-1)
+
+    def _graph_body(self, do_sample, temperature):
+        logits = self.step(self.tok)
+        nxt = self._pick(logits, do_sample, temperature)
+        self.out.index_copy_(0, self.cnt, nxt.view(1, -1))
+        self.tok.copy_(nxt)
+        self.cnt.add_(1)
+
+    def generate(self, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, generator=None, use_graph=True):
+        """Returns a list of B python lists of new token ids (each cut at its first EOS, EOS included like HF).  The decode step is
+        captured once as a hipGraph and replayed (the ~340 launches of a step are launch-bound from Python); sampling inside the
+        graph draws from the default CUDA generator, so a user `generator` selects the eager path.  EOS is checked on the host
+        every 16 steps (sequences that are done keep stepping; their extra tokens are dropped)."""
+        B, dev = self.B, self.lm.device
+        longest = int(self.len.max().item()) + max_new_tokens
+        self.nsplit = max(1, min(64, ((longest + 63) // 64) // 4))
+        self._row0 = torch.arange(B, device=dev, dtype=torch.int64) * self.cap
+        first = self._pick(self.logits, do_sample, temperature, generator)
+        self.out = torch.zeros((max_new_tokens, B), dtype=torch.int64, device=dev)
+        self.out[0] = first
+        self.tok = first.to(torch.int32).contiguous()
+        self.cnt = torch.ones(1, dtype=torch.int64, device=dev)
+        graph = None
+        if use_graph and generator is None and max_new_tokens > 2:
+            snap = (self.tok.clone(), self.len.clone(), self.cnt.clone(), self.out.clone())
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):              # warm-up outside capture (workspaces, function attributes); undone below
+                self._graph_body(do_sample, temperature)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            restore = lambda: [t.copy_(v) for t, v in zip((self.tok, self.len, self.cnt, self.out), snap)]
+            restore()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_body(do_sample, temperature)
+            restore()
+        done_at = [None] * B
+        steps = 1
+        while steps < max_new_tokens:
+            if graph is not None:
+                graph.replay()
+            else:
+                nxt = self._pick(self.step(self.tok), do_sample, temperature, generator)
+                self.out[steps] = nxt
+                self.tok.copy_(nxt)
+                self.cnt.add_(1)
+            steps += 1
+            if eos_token_id is not None and (steps % 16 == 0 or steps == max_new_tokens):
+                col = self.out[:steps].cpu()
+                if all((col[:, b] == eos_token_id).any() for b in range(B)):
+                    break
+        toks = self.out[:steps].cpu().t().tolist()
+        res = []
+        for b in range(B):
+            t = toks[b]
+            if eos_token_id is not None and eos_token_id in t:
+                t = t[:t.index(eos_token_id) + 1]
+            res.append(t)
+        return res
+
+
 class LlavaQwenForCausalLM:
     """Mirror of the reference model object the entry point drives (longva/model/language_model/llava_qwen.py:40-155 +
     LlavaMetaForCausalLM): `.encode_images`, `.get_model().embed_tokens`, `.prepare_inputs_embeddings_for_multimodal`,
@@ -320,6 +437,19 @@ class LlavaQwenForCausalLM:
         new_pos = None if position_ids is None else torch.arange(L, device=self.device).unsqueeze(0)
         new_mask = None if attention_mask is None else torch.ones((1, L), dtype=attention_mask.dtype, device=self.device)
         return None, new_pos, new_mask, past_key_values, out.unsqueeze(0), (None if labels is None else labels_out.unsqueeze(0))
+
+    @torch.no_grad()
+    def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], do_sample=False, temperature=1.0,
+                                            max_new_tokens=256, generator=None, **kwargs):
+        """B independent prompts (one `inputs` ids tensor and one image_embeddings list each, as for generate_with_image_embedding)
+        decoded together by BatchDecoder.  Returns a list of B LongTensors [1, n_b] of new token ids."""
+        prompts = []
+        for ids, img in zip(inputs_list, image_embeddings_list):
+            _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, img, modalities)
+            prompts.append(embeds[0])
+        dec = BatchDecoder(self.lm, prompts, max_new_tokens)
+        toks = dec.generate(max_new_tokens, do_sample, temperature, self.eos_token_id, generator)
+        return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
 
     @torch.no_grad()
     def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=False, temperature=1.0,

@@ -272,7 +272,8 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
     with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), ldo, B, Sq, Skv, Hq, Hkv, Dh,
                                    c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel()),
-                                   q_head_stride, o_head_stride, stream_ptr(q.device)), "sc_attention_f16")
+                                   q_head_stride, o_head_stride, c_int64(q.stride(0) if B > 1 else 0), c_int64(out.stride(0) if B > 1 else 0),
+                                   stream_ptr(q.device)), "sc_attention_f16")
     return out
 
 

@@ -175,10 +175,23 @@ def get_summarize_depth(nodes, interval):
 
 
 def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_clusters, interval, summarizer, input_ids,
-                                              tokenizer, chunked_feature_list, existing_tree=None, conv_templates=None):
+                                              tokenizer, chunked_feature_list, existing_tree=None, conv_templates=None, batch_captions=False):
     """Drop-in for reference utiles.py:489-620: caption every new chunk with the LLM, append depth-0 nodes,
-    then perform AT MOST ONE merge of `interval` sibling nodes (k-means over their concatenated frames)."""
+    then perform AT MOST ONE merge of `interval` sibling nodes (k-means over their concatenated frames).
+    batch_captions=True: the chunks of this call are captioned by ONE batched generate (BatchDecoder: weights stream
+    once per decode step for all chunks) when the summarizer offers `generate_batch_with_image_embedding`; with the reference's
+    sampling settings (temperature 0.1) the texts then depend on the batch-wise RNG order, with do_sample=False they are identical."""
     output_list = []
+    if batch_captions and len(chunked_feature_list) > 1 and hasattr(summarizer, "generate_batch_with_image_embedding"):
+        feats = []
+        for chunk_feature in chunked_feature_list:
+            dimension = chunk_feature[0].shape[-1]
+            feats.append([cat_frames(chunk_feature).reshape(-1, dimension).to(summarizer.device)])
+        with torch.no_grad():
+            outs = summarizer.generate_batch_with_image_embedding([input_ids.to(summarizer.device)] * len(feats), feats, modalities=["video"],
+                                                                  do_sample=True, temperature=0.1, max_new_tokens=128)
+        output_list = [tokenizer.batch_decode(o, skip_special_tokens=True)[0].strip() for o in outs]
+        chunked_feature_list = []
     for chunk_feature in chunked_feature_list:
         dimension = chunk_feature[0].shape[-1]
         chunk_feature = cat_frames(chunk_feature).reshape(-1, dimension).to(summarizer.device)

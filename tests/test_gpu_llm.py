@@ -132,3 +132,31 @@ def test_trimmed_last_layer_gives_same_logits_and_cache():
     assert int(la.argmax()) == int(lb.argmax())
     for ca, cb in zip(a.cache, b.cache):
         assert torch.equal(ca[:37], cb[:37])                                    # K/V of every layer and row are still produced
+
+
+def test_batched_greedy_decode_equals_one_by_one():
+    """BatchDecoder (separate prefill, shared decode steps with M = B GEMMs, one batched attention launch per layer, per-sequence
+    kv_len) produces the tokens of B independent batch-1 generations; prompts of different lengths."""
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    prompts = [emb, emb[:20], emb[5:30]]
+    lm = LM.Qwen2Model(sd, cfg, max_seq=64)
+    single = []
+    for e in prompts:
+        lm.reset_cache()
+        logits, toks = lm.forward(e), []
+        for _ in range(6):
+            toks.append(int(logits.argmax()))
+            logits = lm.forward(lm.embed_tokens(torch.tensor([toks[-1]], device="cuda")))
+        single.append(toks)
+    dec = LM.BatchDecoder(lm, prompts, max_new_tokens=6)
+    assert dec.len.tolist() == [37, 20, 25]
+    batch = dec.generate(6)
+    assert batch == single
+    assert single[0] == d["greedy"].tolist()[:6]                                  # and sequence 0 is still the HF golden
+    # EOS cuts one sequence, the others run on
+    dec2 = LM.BatchDecoder(lm, prompts, max_new_tokens=6)
+    eos = single[1][2]
+    cut = dec2.generate(6, eos_token_id=eos)
+    for got, ref in zip(cut, single):
+        assert got == (ref[:ref.index(eos) + 1] if eos in ref else ref)

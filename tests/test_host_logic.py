@@ -84,6 +84,33 @@ def test_tree_policy_trace(monkeypatch):
             assert {int(k): int(v) for k, v in cnt.items()} == {int(k): v for k, v in upd["count"].items()}
 
 
+def test_batched_captions_build_the_same_tree(monkeypatch):
+    """batch_captions=True routes all chunks of one update through ONE generate_batch_with_image_embedding call; with a
+    deterministic summarizer the tree (texts, shapes, merge) is the one the chunk-by-chunk path builds."""
+    monkeypatch.setattr(U, "weighted_kmeans_feature", oracle_kmeans_feature)
+
+    class BatchSummarizer(FakeSummarizer):
+        batch_calls = 0
+
+        def generate_batch_with_image_embedding(self, ids_list, feats_list, **kw):
+            self.batch_calls += 1
+            assert len(ids_list) == len(feats_list) and all(f[0].dim() == 2 for f in feats_list)
+            return [self.generate_with_image_embedding(i, image_embeddings=f) for i, f in zip(ids_list, feats_list)]
+
+    def build(batch):
+        torch.manual_seed(3)
+        summ, tok, tree = BatchSummarizer(), FakeTok(), None
+        for upd in range(3):
+            buf = [torch.full((1, 2, 4), float(upd * 8 + i)) for i in range(8)]
+            chunked = [buf[i:i + 4] for i in range(0, 8, 4)]
+            tree = U.fast_building_memory_tree_summarize_token([torch.cat(x) for x in chunked], 2, 3, summ, torch.zeros(1, 3, dtype=torch.long), tok,
+                                                               chunked, tree, conv_templates=None, batch_captions=batch)
+        return describe(tree), summ.batch_calls
+    seq, n0 = build(False)
+    bat, n1 = build(True)
+    assert seq == bat and n0 == 0 and n1 == 3
+
+
 def test_get_summarize_depth():
     N = U.MultimodalTreeNode
     nodes = [N(None, "", depth=1)] * 3 + [N(None, "", depth=0)] * 3
