@@ -140,3 +140,21 @@ def test_attention_split_kv_equals_unsplit(Sq, Skv, H, Dh, ns):
     a = ops.attention(q, k, v, H, H, Dh, Dh ** -0.5, False, nsplit=ns)
     ref = _attn_ref(q, k, v, H, H, Dh, Dh ** -0.5, False)
     torch.testing.assert_close(a.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(5000, 4096, 1024, "quick_gelu"), (9000, 2048, 192, "none"), (4099, 8192, 512, "swiglu"), (16640, 1024, 4096, "gelu")])
+def test_gemm_many_tiles_per_workgroup(M, N, K, epi):
+    """more 256x256 tiles than CUs -> the persistent walk (a workgroup computes several tiles, the K-step ring runs across the tile
+    boundary); ragged last tile row (M % 256 != 0), bias + residual, every epilogue.  K = 192 has 6 K-steps (short tiles)."""
+    a, w, b = _rand((M, K), 11), _rand((N, K), 12, K ** -0.5), _rand((N,), 13)
+    if epi == "swiglu":
+        out = ops.gemm(a, w, b, None, epi)
+        z = (a.float() @ w.float().t() + b.float()).view(M, N // 4, 2, 2)            # interleaved (g0, g1, u0, u1) quads
+        ref = (torch.nn.functional.silu(z[:, :, 0]) * z[:, :, 1]).reshape(M, N // 2)
+    else:
+        r = _rand((M, N), 14)
+        out = ops.gemm(a, w, b, r, epi)
+        ref = a.float() @ w.float().t() + b.float()
+        ref = ref * torch.sigmoid(1.702 * ref) if epi == "quick_gelu" else (torch.nn.functional.gelu(ref) if epi == "gelu" else ref)
+        ref = ref + r.float()
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
