@@ -424,11 +424,97 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// skinny M (<= 32 rows): batched decode / few-token projections.  HBM-bound: W is streamed exactly once, straight from global
+// memory into MFMA A-operand registers (every weight element is used once, so LDS staging would only add traffic); the few
+// activation rows are the B operand and come out of L2.  One workgroup = one strip of 16 W rows (= 16 output columns); its 4
+// waves split K four ways and reduce their 16x16 partial tiles through LDS; wave 0 applies bias / activation / residual /
+// SwiGLU and stores.  C/D layout of v_mfma_f32_16x16x32_f16: lane holds D[n = (lane>>4)*4 + r][m = lane&15], i.e. one
+// (g0, g1, u0, u1) quad of the interleaved SwiGLU weight per lane.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32, int MG>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                     const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                     void* __restrict__ Cout, int ldc, int M, int N, int K) {
+    __shared__ float red[3][MG][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rl = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kc = K / 4, k_lo = wave * kc;
+    const _Float16* wp = W + (size_t)(n0 + rl) * (size_t)K + k_lo + g * 8;
+    const _Float16* xp[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        int m = mg * 16 + rl;
+        m = m < M ? m : M - 1;
+        xp[mg] = A + (size_t)m * (size_t)lda + k_lo + g * 8;
+    }
+    sc_f4 acc[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;                          // K-steps in flight per wave: 8 x 16 B of W per lane
+    int k = 0;
+    for (; k + U * 32 <= kc; k += U * 32) {
+        sc_h8 wf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp + k + u * 32));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+                acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u], *reinterpret_cast<const sc_h8*>(xp[mg] + k + u * 32), acc[mg], 0, 0, 0);
+    }
+    for (; k < kc; k += 32) {
+        const sc_h8 wf = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp + k));
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg)
+            acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, *reinterpret_cast<const sc_h8*>(xp[mg] + k), acc[mg], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][mg][r][lane] = acc[mg][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int n = n0 + g * 4;
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mg][r] + red[0][mg][r][lane] + red[1][mg][r][lane] + red[2][mg][r][lane] + (bias ? (float)bias[n + r] : 0.f);
+        const int m = mg * 16 + rl;
+        if (m >= M) continue;
+        if (EPI == SC_EPI_SWIGLU) {
+            const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[2], o1 = v[1] / (1.0f + __expf(-v[1])) * v[3];
+            const sc_h2 o = {(_Float16)o0, (_Float16)o1};
+            *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = epi_apply(v[r], EPI);
+            if (R) { const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n); for (int r = 0; r < 4; ++r) v[r] += (float)r4[r]; }
+            if (OUT_F32) *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+            else *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
     static int force = -1;                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
+    if (force == 0 && M <= 32 && K % 128 == 0 && a_grp == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0)) {      // few rows: stream W once
+        const dim3 grid((unsigned)(N / 16)), block(256);
+#define SC_LSK(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny<EPI, F32, MGV>), grid, block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
+                                              (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K)
+        if (M <= 16) { if (out_f32) SC_LSK(true, 1); else SC_LSK(false, 1); }
+        else { if (out_f32) SC_LSK(true, 2); else SC_LSK(false, 2); }
+#undef SC_LSK
+        SC_CHECK_LAUNCH("sc_gemm_f16");
+        return SC_OK;
+    }
     const bool big = force == 256 || force == 2561 || (force != 128 && M >= 1024);
     const bool wide_ok = out_f32 || (ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);      // 16-byte epilogue stores
     if (big && wide_ok && N % BN2 == 0 && K % BK2 == 0) {

@@ -158,3 +158,22 @@ def test_gemm_many_tiles_per_workgroup(M, N, K, epi):
         ref = ref * torch.sigmoid(1.702 * ref) if epi == "quick_gelu" else (torch.nn.functional.gelu(ref) if epi == "gelu" else ref)
         ref = ref + r.float()
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 17, 26, 32])
+@pytest.mark.parametrize("N,K,epi", [(3584, 3584, "none"), (1024, 1536, "gelu"), (512, 18944, "none"), (768, 256, "swiglu"), (256, 384, "quick_gelu")])
+def test_gemm_skinny_rows(M, N, K, epi):
+    """M <= 32: the weight-streaming kernel (W read once from global memory into MFMA operands, K split over the 4 waves of a
+    workgroup); every epilogue, bias + residual, fp16 and fp32 outputs."""
+    a, w, b = _rand((M, K), 21), _rand((N, K), 22, K ** -0.5), _rand((N,), 23)
+    z = a.float() @ w.float().t() + b.float()
+    if epi == "swiglu":
+        out = ops.gemm(a, w, b, None, epi)
+        q = z.view(M, N // 4, 2, 2)
+        ref = (torch.nn.functional.silu(q[:, :, 0]) * q[:, :, 1]).reshape(M, N // 2)
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+        return
+    r = _rand((M, N), 24)
+    ref = z * torch.sigmoid(1.702 * z) if epi == "quick_gelu" else (torch.nn.functional.gelu(z) if epi == "gelu" else z)
+    torch.testing.assert_close(ops.gemm(a, w, b, r, epi).float(), ref + r.float(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(ops.gemm(a, w, b, None, epi, out_f32=True), ref, rtol=1e-3, atol=1e-3)
