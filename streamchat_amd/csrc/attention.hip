@@ -171,16 +171,18 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     const int t_hi = (t_lo + per) < nt ? (t_lo + per) : nt;
     if (t_lo < t_hi) stage(0, t_lo);
     __syncthreads();
-    const sc_f2 sc2 = {scale_log2, scale_log2};
-    // m_run is the REFERENCE max of a row in the scaled log2 domain: p = 2^(s*scale - m_run); O and l are relative to the same
-    // reference, so the final O / l does not depend on it.  Two tile bodies share the loop:
-    //   SLOW (general): masks, moves the reference to the true running max and rescales O (exact online softmax step);
-    //   FAST: no mask arithmetic, no O rescale - valid while every kv of the tile is visible to every query of the wave and no
-    //         row max outgrows its reference by more than 2^8 (p <= 256, far inside fp16).  After the first tile or two that is
-    //         nearly every tile of a long sequence.  The fast body is a loop of its own in which O is only ever touched by the
-    //         accumulating MFMAs; a rescale branch inside one shared body made the compiler keep two copies of O (64 extra
-    //         VGPRs and 32..66 register moves per tile).  A fast tile that finds a row needing a new reference leaves the loop
-    //         BEFORE touching O or l and is redone by the slow body (its K/V tile is still in LDS, its prefetch already issued).
+    // m_run is the REFERENCE max of a row in the scaled log2 domain: p = 2^(s - m_run); O and l are relative to the same reference,
+    // so the final O / l does not depend on it.  Two tile bodies share the loop:
+    //   GENERAL: masks, moves the reference to the true running max and rescales O (exact online softmax step);
+    //   STEADY STATE: valid while every kv of the tile is visible to every query of the wave.  The reference stays where the last
+    //         general tile left it, O is only ever touched
+    //         by the accumulating MFMAs (a rescale branch inside one shared body made the compiler keep two copies of O: +64
+    //         VGPRs, 32..66 moves per tile), and there is NO row max at all: fp16 P holds 2^-24 .. 2^16 around the reference, i.e.
+    //         it only fails when a later score exceeds the first tile's row max by a factor e^11 - that is detected at the end
+    //         (inf / NaN in O or l) and the block redoes its rows with the general body on every tile.
+    //         Per tile that removes 28 max + 2 permlane swaps per q-block from an issue-bound loop.  (Pre-scaling Q by scale*log2 e
+    //         and starting the accumulators at -m_ref would also remove the 16 packed FMAs, but the extra fp16 rounding of q*c moves a
+    //         score by |s| * 2^-11 / sqrt(Dh): fine for |s| < 50, 9 % on p at the |s| ~ 2000 of the overflow test.)
     auto s_phase = [&](const char* sk, sc_f4 (&s)[4][QB]) {
         constexpr int NKF = 4 * DS;
         sc_h8 kfr[2];
@@ -207,11 +209,12 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
         const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        tmax = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-        return tmax * scale_log2;                                                    // scale > 0: max commutes with scaling
+        return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) * scale_log2;      // scale > 0: max commutes with scaling
     };
-    auto p_phase = [&](const sc_f4 (&s)[4][QB], int qb, float m_use, sc_h8 (&pf)[QB][2]) {
-        const sc_f2 m2 = {m_use, m_use};
+    // P = 2^(s*scale - m) -> fp16 MFMA operand + row sums (one packed FMA per pair of scores)
+    const sc_f2 sc2 = {scale_log2, scale_log2};
+    auto p_phase = [&](const sc_f4 (&s)[4][QB], int qb, float m_sub, sc_h8 (&pf)[QB][2]) {
+        const sc_f2 m2 = {m_sub, m_sub};
         sc_f2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kvb = 0; kvb < 4; ++kvb)
@@ -247,61 +250,82 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         return m;
     };
 
-    int t = t_lo;
-    bool staged = false;                       // tile t + 1 already requested by a fast iteration that bailed out
-    while (t < t_hi) {
-        // ---------------- SLOW tile ----------------
-        {
-            const int cur = (t - t_lo) & 1;
-            if (!staged && t + 1 < t_hi) stage(cur ^ 1, t + 1);
-            staged = false;
-            const char* sk = smem + cur * STAGE;
-            sc_f4 s[4][QB];
-            s_phase(sk, s);
-            sc_h8 pf[QB][2];
-            const int kv_t0 = t * KVT + g * 4;
+    // pass 0: general tiles + the steady-state loop (no row max, no reference check: see the note above).  If any P of the block
+    // overflowed fp16 (a score more than 2^16 above its row's reference) O or l is inf / NaN at the end; the WHOLE block then
+    // redoes its rows in pass 1 with the general body only (exact online softmax on every tile).
+    for (int pass = 0; pass < 2; ++pass) {
+        int t = t_lo;
+        while (t < t_hi) {
+            // ---------------- general tile ----------------
+            {
+                const int cur = (t - t_lo) & 1;
+                if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
+                const char* sk = smem + cur * STAGE;
+                sc_f4 s[4][QB];
+                s_phase(sk, s);
+                sc_h8 pf[QB][2];
+                const int kv_t0 = t * KVT + g * 4;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const int qpos = qw0 + qb * 16 + rl + coff;
+                for (int qb = 0; qb < QB; ++qb) {
+                    const int qpos = qw0 + qb * 16 + rl + coff;
 #pragma unroll
-                for (int kvb = 0; kvb < 4; ++kvb)
+                    for (int kvb = 0; kvb < 4; ++kvb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kv = kv_t0 + kvb * 16 + r;
-                        const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
-                        s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
-                    }
-                const float m_new = fmaxf(m_run[qb], row_max(s, qb));
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);       // 1 when the reference did not move, 0 at the start
-                m_run[qb] = m_new;
-                l_run[qb] *= alpha;
+                        for (int r = 0; r < 4; ++r) {
+                            const int kv = kv_t0 + kvb * 16 + r;
+                            const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                            s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
+                        }
+                    const float m_new = fmaxf(m_run[qb], row_max(s, qb));
+                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);   // 1 when the reference did not move, 0 at the start
+                    m_run[qb] = m_new;
+                    l_run[qb] *= alpha;
 #pragma unroll
-                for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
-                p_phase(s, qb, m_use, pf);
+                    for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
+                    p_phase(s, qb, m_use, pf);
+                }
+                pv_phase(sk + TILE, pf);
+                __syncthreads();
+                ++t;
             }
-            pv_phase(sk + TILE, pf);
-            __syncthreads();
-            ++t;
-        }
-        // ---------------- FAST tiles ----------------
-        while (t < t_hi && !masked(t)) {
-            const int cur = (t - t_lo) & 1;
-            if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
-            const char* sk = smem + cur * STAGE;
-            sc_f4 s[4][QB];
-            s_phase(sk, s);
-            bool need = false;
+            if (pass == 1) continue;
+            // ---------------- steady state ----------------
+            bool ok = true;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) need = need || (row_max(s, qb) > m_run[qb] + 8.0f);
-            if (__any(need)) { staged = true; break; }
-            sc_h8 pf[QB][2];
+            for (int qb = 0; qb < QB; ++qb) ok = ok && (m_run[qb] > -INFINITY);
+            if (!__all(ok)) continue;                                                 // a row without any visible key yet
+            while (t < t_hi && !masked(t)) {
+                const int cur = (t - t_lo) & 1;
+                if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
+                const char* sk = smem + cur * STAGE;
+                sc_f4 s[4][QB];
+                s_phase(sk, s);
+                sc_h8 pf[QB][2];
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) p_phase(s, qb, m_run[qb], pf);
-            pv_phase(sk + TILE, pf);
-            __syncthreads();
-            ++t;
+                for (int qb = 0; qb < QB; ++qb) p_phase(s, qb, m_run[qb], pf);
+                pv_phase(sk + TILE, pf);
+                __syncthreads();
+                ++t;
+            }
         }
+        if (pass == 1) break;
+        float chk = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            chk += l_run[qb] * 0.f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) chk += (o[db][qb][0] + o[db][qb][1] + o[db][qb][2] + o[db][qb][3]) * 0.f;        // inf, NaN -> NaN
+        }
+        if (!__syncthreads_or(chk != chk)) break;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int jj = 0; jj < QB; ++jj) o[i][jj] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+        if (t_lo < t_hi) stage(0, t_lo);
+        __syncthreads();
     }
 
     // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----

@@ -114,6 +114,25 @@ def test_attention_online_softmax_rescale_branch():
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("Dh,causal", [(64, False), (128, True)])
+def test_attention_late_huge_score_forces_the_exact_pass(Dh, causal):
+    """The steady-state loop keeps the first tile's row max as the softmax reference and takes no row max afterwards; a later score
+    more than 2^16 above it overflows fp16 P.  That must be detected (inf / NaN in O or l at the end of the block) and the block
+    redone with the exact online softmax: here keys in the 5th tile score ~e^60 above everything before them."""
+    B, S, H = 1, 512, 2
+    q, k, v = _rand((B, S, H * Dh), 5), _rand((B, S, H * Dh), 6), _rand((B, S, H * Dh), 7)
+    q[0, 300:] *= 4.0
+    k[0, 290] = q[0, 400] * 3.0                    # q_i . k_290 ~ 12 |q|^2 for the late queries
+    scale = 0.5
+    out = ops.attention(q, k, v, H, H, Dh, scale, causal)
+    ref = _attn_ref(q, k, v, H, H, Dh, scale, causal)
+    assert torch.isfinite(out).all()
+    s_max = (q[0, 400, :Dh].float() @ k[0, 290, :Dh].float()) * scale
+    s_first = ((q[0, 400, :Dh].float() @ k[0, :64, :Dh].float().t()) * scale).max()
+    assert (s_max - s_first) * 1.4427 > 20                                          # the test really is beyond fp16 range
+    torch.testing.assert_close(out.float(), ref, rtol=3e-3, atol=3e-3)
+
+
 @pytest.mark.parametrize("N,K", [(3584, 3584), (1024, 3584), (152064, 3584), (3584, 18944), (130, 264)])
 def test_gemv_vs_torch_fp32(N, K):
     w, x, b, r = _rand((N, K), 1, K ** -0.5), _rand((K,), 2), _rand((N,), 3), _rand((N,), 4)
