@@ -37,7 +37,7 @@ __device__ __forceinline__ void lds_load16(const void* base, int extent, char* l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int DH, int QB, bool CAUSAL>
+template <int DH, int QB, bool CAUSAL, int CH>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
                                               int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
@@ -183,14 +183,23 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     //         Per tile that removes 28 max + 2 permlane swaps per q-block from an issue-bound loop.  (Pre-scaling Q by scale*log2 e
     //         and starting the accumulators at -m_ref would also remove the 16 packed FMAs, but the extra fp16 rounding of q*c moves a
     //         score by |s| * 2^-11 / sqrt(Dh): fine for |s| < 50, 9 % on p at the |s| ~ 2000 of the overflow test.)
-    auto s_phase = [&](const char* sk, sc_f4 (&s)[4][QB]) {
-        constexpr int NKF = 4 * DS;
+    // The unit of S / softmax / P.V work is a CHUNK of CH kv rows (CH = 64: the whole tile; CH = 32: half tiles).  With half tiles S
+    // and P of only 32 rows are live at a time, which is what lets a wave carry QB = 3 q-blocks (48 queries) in 256 VGPRs at
+    // Dh = 128: every K / V fragment read from LDS then feeds three MFMAs instead of two.  The loop is LDS-bandwidth bound (a
+    // fragment is 1 KB; at QB = 2 the LDS pipe needs as many cycles per tile as the MFMA pipe - tools/probes/probe_phases2/3.hip:
+    // 12.1 -> 10.0 ns per MFMA going from 2 to 3 MFMAs per fragment); on the real kernel: +6 % at 26 k tokens, but half tiles alone
+    // cost 3 % (shorter MFMA bursts) and 192-query blocks waste a quarter of a 577-token ViT sequence, so short sequences keep
+    // CH = 64 / QB = 2.
+    constexpr int NCH = KVT / CH, KVB = CH / 16, PC = CH / 32;
+    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB]) {
+        constexpr int NKF = KVB * DS;
+        const char* skc = sk + c * KVB * KBLK;
         sc_h8 kfr[2];
-        kfr[0] = *reinterpret_cast<const sc_h8*>(sk + k_off[0]);
+        kfr[0] = *reinterpret_cast<const sc_h8*>(skc + k_off[0]);
 #pragma unroll
         for (int i = 0; i < NKF; ++i) {
             const int kvb = i / DS, ds = i % DS;
-            if (i + 1 < NKF) kfr[(i + 1) & 1] = *reinterpret_cast<const sc_h8*>(sk + ((i + 1) / DS) * KBLK + k_off[(i + 1) % DS]);
+            if (i + 1 < NKF) kfr[(i + 1) & 1] = *reinterpret_cast<const sc_h8*>(skc + ((i + 1) / DS) * KBLK + k_off[(i + 1) % DS]);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const sc_f4 acc = ds == 0 ? sc_f4{0.f, 0.f, 0.f, 0.f} : s[kvb][qb];
@@ -198,10 +207,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
             }
         }
     };
-    auto row_max = [&](const sc_f4 (&s)[4][QB], int qb) {
+    auto row_max = [&](const sc_f4 (&s)[KVB][QB], int qb) {
         float tmax = -INFINITY;
 #pragma unroll
-        for (int kvb = 0; kvb < 4; ++kvb)
+        for (int kvb = 0; kvb < KVB; ++kvb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
         // max over the 4 lane groups holding this query column: two VALU row swaps (v_permlane16_swap / v_permlane32_swap with the
@@ -213,11 +222,11 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     };
     // P = 2^(s*scale - m) -> fp16 MFMA operand + row sums (one packed FMA per pair of scores)
     const sc_f2 sc2 = {scale_log2, scale_log2};
-    auto p_phase = [&](const sc_f4 (&s)[4][QB], int qb, float m_sub, sc_h8 (&pf)[QB][2]) {
+    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC]) {
         const sc_f2 m2 = {m_sub, m_sub};
         sc_f2 ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int kvb = 0; kvb < 4; ++kvb)
+        for (int kvb = 0; kvb < KVB; ++kvb)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 const sc_f2 x = sc_f2{s[kvb][qb][r], s[kvb][qb][r + 1]} * sc2 - m2;
@@ -228,19 +237,19 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
             }
         l_run[qb] += ps2[0] + ps2[1];
     };
-    auto pv_phase = [&](const char* sv, const sc_h8 (&pf)[QB][2]) {
+    auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC]) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int pc = 0; pc < PC; ++pc) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const char* vp = sv + c * 32 * VROW + v_off[db];
+                const char* vp = sv + (c * PC + pc) * 32 * VROW + v_off[db];
                 const sc_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp));
                 const sc_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp + 16 * VROW));
                 typedef short sc_s8 __attribute__((ext_vector_type(8)));
                 const sc_s8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const sc_h8 vf = __builtin_bit_cast(sc_h8, v8);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][c], o[db][qb], 0, 0, 0);
+                for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][pc], o[db][qb], 0, 0, 0);
             }
         }
     };
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 
     // pass 0: general tiles + the steady-state loop (no row max, no reference check: see the note above).  If any P of the block
     // overflowed fp16 (a score more than 2^16 above its row's reference) O or l is inf / NaN at the end; the WHOLE block then
-    // redoes its rows in pass 1 with the general body only (exact online softmax on every tile).
+    // redoes its rows in pass 1 with the general body only (exact online softmax on every chunk).
     for (int pass = 0; pass < 2; ++pass) {
         int t = t_lo;
         while (t < t_hi) {
@@ -261,31 +270,34 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 const int cur = (t - t_lo) & 1;
                 if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
                 const char* sk = smem + cur * STAGE;
-                sc_f4 s[4][QB];
-                s_phase(sk, s);
-                sc_h8 pf[QB][2];
-                const int kv_t0 = t * KVT + g * 4;
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    const int qpos = qw0 + qb * 16 + rl + coff;
+                for (int c = 0; c < NCH; ++c) {
+                    sc_f4 s[KVB][QB];
+                    s_part(sk, c, s);
+                    sc_h8 pf[QB][PC];
+                    const int kv_t0 = t * KVT + c * CH + g * 4;
 #pragma unroll
-                    for (int kvb = 0; kvb < 4; ++kvb)
+                    for (int qb = 0; qb < QB; ++qb) {
+                        const int qpos = qw0 + qb * 16 + rl + coff;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int kv = kv_t0 + kvb * 16 + r;
-                            const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
-                            s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
-                        }
-                    const float m_new = fmaxf(m_run[qb], row_max(s, qb));
-                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);   // 1 when the reference did not move, 0 at the start
-                    m_run[qb] = m_new;
-                    l_run[qb] *= alpha;
+                        for (int kvb = 0; kvb < KVB; ++kvb)
 #pragma unroll
-                    for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
-                    p_phase(s, qb, m_use, pf);
+                            for (int r = 0; r < 4; ++r) {
+                                const int kv = kv_t0 + kvb * 16 + r;
+                                const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                                s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
+                            }
+                        const float m_new = fmaxf(m_run[qb], row_max(s, qb));
+                        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);       // 1 when the reference did not move, 0 at the start
+                        m_run[qb] = m_new;
+                        l_run[qb] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
+                        p_part(s, qb, m_use, pf);
+                    }
+                    pv_part(sk + TILE, c, pf);
                 }
-                pv_phase(sk + TILE, pf);
                 __syncthreads();
                 ++t;
             }
@@ -299,12 +311,15 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 const int cur = (t - t_lo) & 1;
                 if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
                 const char* sk = smem + cur * STAGE;
-                sc_f4 s[4][QB];
-                s_phase(sk, s);
-                sc_h8 pf[QB][2];
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) p_phase(s, qb, m_run[qb], pf);
-                pv_phase(sk + TILE, pf);
+                for (int c = 0; c < NCH; ++c) {
+                    sc_f4 s[KVB][QB];
+                    s_part(sk, c, s);
+                    sc_h8 pf[QB][PC];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf);
+                    pv_part(sk + TILE, c, pf);
+                }
                 __syncthreads();
                 ++t;
             }
@@ -396,7 +411,7 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
     O[(size_t)b * (size_t)o_bs + (size_t)q * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
 }
 
-template <int DH, int QB>
+template <int DH, int QB, int CH = 64>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
                 int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s) {
     const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16), G = Hq / Hkv;
@@ -405,10 +420,10 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
     const size_t lds = 2 * 2 * KVT * DH * 2;
     const float sl2 = scale * 1.4426950408889634f;
     if (causal)
-        hipLaunchKernelGGL((k_attn<DH, QB, true>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
+        hipLaunchKernelGGL((k_attn<DH, QB, true, CH>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
                            ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
     else
-        hipLaunchKernelGGL((k_attn<DH, QB, false>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
+        hipLaunchKernelGGL((k_attn<DH, QB, false, CH>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
                            ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
     if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
     SC_CHECK_LAUNCH("sc_attention_f16");
@@ -441,6 +456,8 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     const long qbs = q_batch_stride > 0 ? (long)q_batch_stride : (long)Sq * ldq, obs = o_batch_stride > 0 ? (long)o_batch_stride : (long)Sq * ldo;
     SC_REQUIRE(qbs % 8 == 0 && obs % 4 == 0, "sc_attention_f16: batch strides must be multiples of 8 (q) / 4 (out)");
     if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
+    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles
+    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
     if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
     return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
 }

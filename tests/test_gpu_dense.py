@@ -114,12 +114,23 @@ def test_attention_online_softmax_rescale_branch():
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,Sq,Skv,Hq,Hkv,causal,pad", [(1, 2304, 2304, 4, 2, True, False), (2, 2050, 2500, 2, 2, False, True), (1, 2048, 3000, 7, 1, True, False)])
+def test_attention_long_dh128_three_qblock_path(B, Sq, Skv, Hq, Hkv, causal, pad):
+    """Sq >= 2048 at Dh = 128 takes the 48-queries-per-wave / half-tile variant (192-query blocks): ragged last block, GQA, causal
+    with Skv > Sq, padding mask."""
+    q, k, v = _rand((B, Sq, Hq * 128), 31), _rand((B, Skv, Hkv * 128), 32), _rand((B, Skv, Hkv * 128), 33)
+    kv_len = torch.tensor([Skv - 37, 1500][:B], device="cuda", dtype=torch.int32) if pad else None
+    out = ops.attention(q, k, v, Hq, Hkv, 128, 0.09, causal, kv_len)
+    ref = _attn_ref(q, k, v, Hq, Hkv, 128, 0.09, causal, kv_len)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("Dh,causal", [(64, False), (128, True)])
 def test_attention_late_huge_score_forces_the_exact_pass(Dh, causal):
     """The steady-state loop keeps the first tile's row max as the softmax reference and takes no row max afterwards; a later score
     more than 2^16 above it overflows fp16 P.  That must be detected (inf / NaN in O or l at the end of the block) and the block
     redone with the exact online softmax: here keys in the 5th tile score ~e^60 above everything before them."""
-    B, S, H = 1, 512, 2
+    B, S, H = 1, (2112 if Dh == 128 else 512), 2                                  # Dh = 128: long enough for the 3-q-block variant
     q, k, v = _rand((B, S, H * Dh), 5), _rand((B, S, H * Dh), 6), _rand((B, S, H * Dh), 7)
     q[0, 300:] *= 4.0
     k[0, 290] = q[0, 400] * 3.0                    # q_i . k_290 ~ 12 |q|^2 for the late queries

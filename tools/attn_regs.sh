@@ -5,6 +5,6 @@ python3 - <<'PY'
 import re
 t=open('/tmp/attn2.s').read()
 for m in re.finditer(r'\.name:\s+(\S*k_attnI\S+)\n(?:.*\n)*?\s+\.sgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)', t):
-    n=re.search(r'k_attnILi(\d+)ELi(\d+)ELb(\d)',m.group(1)).groups()
-    print('DH=%s QB=%s causal=%s  sgpr=%s vgpr=%s spill=%s'%(n+m.groups()[1:]))
+    n=re.search(r'k_attnILi(\d+)ELi(\d+)ELb(\d)ELi(\d+)',m.group(1)).groups()
+    print('DH=%s QB=%s causal=%s CH=%s  sgpr=%s vgpr=%s spill=%s'%(n+m.groups()[1:]))
 PY
