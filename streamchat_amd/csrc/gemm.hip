@@ -182,14 +182,27 @@ constexpr int NSTAGE2 = 4;
 
 __device__ __forceinline__ int swzF(int x) { return (0x78 >> (2 * (x & 3))) & 3; }
 
+// 16-byte LDS-DMA through a raw buffer resource (base, extent in bytes): lane address = base + voff + soff, destination = the
+// wave-uniform LDS pointer + lane * 16; lanes past the extent write zeros.  (A free function: an opaque __amdgpu_buffer_rsrc_t
+// inside a lambda of the kernel silently drops the kernel's host stub.)
+__device__ __forceinline__ void lds_load16(const void* base, unsigned extent, char* lds, unsigned voff, unsigned soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
 // WR = wave rows: 2 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, one workgroup per CU, DMA 3 steps ahead);
 //                  1 -> 128x256 tile, 4 waves, 3-slot ring (72 KiB, TWO workgroups per CU, DMA 2 steps ahead): for short-K GEMMs
 //                       (ViT, K = 1024: 32 steps) one workgroup's prologue / epilogue then overlaps the other's main loop.
-template <int EPI, bool OUT_F32, int WR>
+// PERSIST: the grid is one workgroup per CU and every workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... (same tile order and
+//          XCD affinity as the one-tile-per-workgroup launch).  The K-step ring simply continues across the tile boundary: the DMA
+//          issued DIST steps ahead in the last steps of a tile fetches the first steps of the NEXT tile, so its data lands while the
+//          epilogue (no LDS) stores the finished tile, and the next tile starts without the ~2 us cold prologue (K = 1024: 32 steps
+//          per tile, the prologue was ~9 % of a tile).
+template <int EPI, bool OUT_F32, int WR, bool PERSIST = false>
 __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                          const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
                                                          void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int a_grp,
-                                                         int a_grp_stride, int a_grp_off, int GM) {
+                                                         int a_grp_stride, int a_grp_off, int GM, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = WR * 256;                    // threads
     constexpr int NS = WR == 2 ? 4 : 3;             // ring slots
@@ -198,14 +211,18 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     constexpr int AH = BMx * BK2 * 2;               // A bytes per stage
     constexpr int STG = AH + HALF2;                 // + W bytes per stage (256 rows)
     constexpr int GW = 4 / WR;                      // W granules per thread per stage (A: always 2)
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    // grouped raster: GM tile-rows per group, tile-row index fastest, so the tiles an XCD runs concurrently form a compact patch
-    const int tilesM = nwg / tilesN;
-    const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
-    const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
-    const int tm = grp * GM + within % gm, tn = within / gm;
+    const int nwg = PERSIST ? ntiles : (int)gridDim.x;
+    auto tile_of = [&](int bid, int& tm_, int& tn_) {
+        const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        // grouped raster: GM tile-rows per group, tile-row index fastest, so the tiles an XCD runs concurrently form a compact patch
+        const int tilesM = nwg / tilesN;
+        const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
+        const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
+        tm_ = grp * GM + within % gm; tn_ = within / gm;
+    };
+    int vb = blockIdx.x, tm, tn;
+    tile_of(vb, tm, tn);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -214,35 +231,64 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     // staging: granule q = j*NT + tid -> row q>>2, physical slot q&3
     const _Float16* a_src[2];
     const _Float16* w_src[GW];
+    // PERSIST: no per-lane pointers at all - constant per-lane 32-bit offsets inside a tile + uniform (SGPR) tile / K-step offsets
+    // through buffer_load ... lds; rows >= M are out of the resource's extent and arrive as zeros (they are never stored).
+    unsigned a_vo[2], w_vo[GW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = j * NT + tid;
-        const int r = q >> 2;
-        const int sl = (q & 3) ^ swzF(r >> 2);
-        int ar = tm * BMx + r;
-        ar = ar < M ? ar : M - 1;
-        if (a_grp > 0) ar = (ar / a_grp) * a_grp_stride + a_grp_off + (ar % a_grp);
-        a_src[j] = A + (size_t)ar * (size_t)lda + sl * 8;
-    }
+    for (int j = 0; j < 2; ++j) { const int q = j * NT + tid, r = q >> 2; a_vo[j] = ((unsigned)r * (unsigned)lda + (unsigned)(((q & 3) ^ swzF(r >> 2)) * 8)) * 2u; }
 #pragma unroll
-    for (int j = 0; j < GW; ++j) {
-        const int q = j * NT + tid;
-        const int r = q >> 2;
-        const int sl = (q & 3) ^ swzF(r >> 2);
-        w_src[j] = W + (size_t)(tn * BN2 + r) * (size_t)K + sl * 8;
-    }
-    auto slot_of = [&](int ks) { return NS == 4 ? (ks & 3) : (ks % 3); };
+    for (int j = 0; j < GW; ++j) { const int q = j * NT + tid, r = q >> 2; w_vo[j] = ((unsigned)r * (unsigned)K + (unsigned)(((q & 3) ^ swzF(r >> 2)) * 8)) * 2u; }
+    const unsigned a_ext = (unsigned)M * (unsigned)lda * 2u, w_ext = (unsigned)N * (unsigned)K * 2u;
+    int tm_nx = 0, tn_nx = 0;                       // PERSIST: next tile of this workgroup
+    auto set_src = [&](int tm_, int tn_, const _Float16* (&as)[2], const _Float16* (&ws)[GW]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = j * NT + tid;
+            const int r = q >> 2;
+            const int sl = (q & 3) ^ swzF(r >> 2);
+            int ar = tm_ * BMx + r;
+            ar = ar < M ? ar : M - 1;
+            if (a_grp > 0) ar = (ar / a_grp) * a_grp_stride + a_grp_off + (ar % a_grp);
+            as[j] = A + (size_t)ar * (size_t)lda + sl * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {
+            const int q = j * NT + tid;
+            const int r = q >> 2;
+            const int sl = (q & 3) ^ swzF(r >> 2);
+            ws[j] = W + (size_t)(tn_ * BN2 + r) * (size_t)K + sl * 8;
+        }
+    };
+    if (!PERSIST) set_src(tm, tn, a_src, w_src);
+    const int nk = K / BK2;
+    int sb = 0;                                     // ring slot of K-step 0 of the current tile (PERSIST: the ring runs on across tiles)
+    bool has_next = false;
+    auto slot_of = [&](int ks) { return NS == 4 ? ((sb + ks) & 3) : (ks % 3); };
     auto issue_w = [&](int ks) {
         char* base = smem + slot_of(ks) * STG + AH;
+        if (PERSIST) {
+            const bool nx = ks >= nk;                // wave-uniform: the step belongs to the next tile
+            const unsigned so = ((unsigned)(nx ? tn_nx : tn) * (unsigned)(BN2 * K) + (unsigned)((nx ? ks - nk : ks) * BK2)) * 2u;
 #pragma unroll
-        for (int j = 0; j < GW; ++j)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(w_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
+            for (int j = 0; j < GW; ++j) lds_load16(W, w_ext, base + (j * NT + wave * 64) * 16, w_vo[j], so);
+        } else {
+#pragma unroll
+            for (int j = 0; j < GW; ++j)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(w_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
+        }
     };
     auto issue_a = [&](int ks) {
         char* base = smem + slot_of(ks) * STG;
+        if (PERSIST) {
+            const bool nx = ks >= nk;
+            const unsigned so = ((unsigned)(nx ? tm_nx : tm) * (unsigned)(BMx * lda) + (unsigned)((nx ? ks - nk : ks) * BK2)) * 2u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
+            for (int j = 0; j < 2; ++j) lds_load16(A, a_ext, base + (j * NT + wave * 64) * 16, a_vo[j], so);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + ks * BK2), (lds_ptr_t)(base + (j * NT + wave * 64) * 16), 16, 0, 0);
+        }
     };
     // wait until at most `steps_in_flight` K-steps of this thread's DMA are outstanding (2 + GW issues per step)
     auto wait_steps = [&](int steps_in_flight) {
@@ -250,6 +296,15 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
         else if (steps_in_flight == 1) { if (GW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else { if (GW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
     };
+
+    // PERSIST, first two K-steps after an epilogue: the loads being waited for (issued before the epilogue) are OLDER than the
+    // epilogue's 16 (SwiGLU: 8) global stores, which share vmcnt on gfx9 - allow those stores (and the one younger DMA step) to stay
+    // in flight, otherwise the wave stalls until its C tile has reached memory and the stores never overlap the next tile's MFMAs.
+    auto wait_after_epilogue = [&]() {
+        if (EPI == SC_EPI_SWIGLU) { if (GW == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+        else { if (GW == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }
+    };
+    int relax = 0;                                  // K-steps left that may use it (0 after an edge tile: fewer stores were issued)
 
     const int rl = lane & 15, g = lane >> 4;
     const int frag = rl * 64 + ((g ^ swzF(rl >> 2)) << 4);
@@ -262,7 +317,6 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK2;
     // ---- prologue: steps 0..DIST-1 in flight, step 0 landed for every wave, first fragments in registers ----
     issue_w(0); issue_a(0);
     if (nk > 1) { issue_w(1); issue_a(1); }
@@ -288,7 +342,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], alo[i], acc[i][j], 0, 0, 0);
         if (SC_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         // step ks+1 must have landed for everyone (steps ks+2 .. ks+DIST-1 may stay in flight); slot of step ks-1 is free afterwards
-        if (steady) wait_steps(DIST - 2);
+        if (steady) { if (decltype(sid)::value >= 7) wait_after_epilogue(); else wait_steps(DIST - 2); }
         else { const int newest = (ks + DIST - 1) < (nk - 1) ? (ks + DIST - 1) : (nk - 1); wait_steps(newest - (ks + 1)); }
         __builtin_amdgcn_s_barrier();
         if (steady) { issue_w(ks + DIST); issue_a(ks + DIST); }
@@ -315,7 +369,23 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
             for (int i = 0; i < (12 - (GW - 2)) / SC_GEMM_MPL; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, SID); __builtin_amdgcn_sched_group_barrier(0x100, SC_GEMM_MPL, SID); }
         }
     };
+    for (;;) {                                           // PERSIST: tiles of this workgroup; otherwise exactly one pass
+    if (PERSIST) {
+        has_next = vb + (int)gridDim.x < ntiles;
+        if (has_next) tile_of(vb + gridDim.x, tm_nx, tn_nx);
+    }
     int ks = 0;
+    if (PERSIST && has_next) {
+        if (relax) {                                     // first pair after a full tile's epilogue: its stores may stay in flight
+            kstep(std::integral_constant<int, 7>{}, 0, true, aloA, ahiA, bcA, aloB, ahiB, bcB);
+            kstep(std::integral_constant<int, 8>{}, 1, true, aloB, ahiB, bcB, aloA, ahiA, bcA);
+            ks = 2;
+        }
+        for (; ks + 1 < nk; ks += 2) {                   // every step is steady: steps >= nk of the issue stream are the next tile's
+            kstep(std::integral_constant<int, 5>{}, ks, true, aloA, ahiA, bcA, aloB, ahiB, bcB);
+            kstep(std::integral_constant<int, 6>{}, ks + 1, true, aloB, ahiB, bcB, aloA, ahiA, bcA);
+        }
+    } else {
     for (; ks + 1 + DIST < nk; ks += 2) {                // steady state: both steps of the pair still issue DMA
         kstep(std::integral_constant<int, 0>{}, ks, true, aloA, ahiA, bcA, aloB, ahiB, bcB);
         kstep(std::integral_constant<int, 1>{}, ks + 1, true, aloB, ahiB, bcB, aloA, ahiA, bcA);
@@ -325,6 +395,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
         kstep(std::integral_constant<int, 3>{}, ks + 1, false, aloB, ahiB, bcB, aloA, ahiA, bcA);
     }
     if (ks < nk) kstep(std::integral_constant<int, 4>{}, ks, false, aloA, ahiA, bcA, aloB, ahiB, bcB);
+    }
 
     // ---- epilogue.  Each lane owns C[m = m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3]; bias / activation / residual are applied in
     // fp32 in that ownership.  The fp16 results are then exchanged between the four 16-lane rows of the wave with
@@ -421,6 +492,17 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
                 }
             }
         }
+    }
+    if (!PERSIST || !has_next) break;
+    // next tile of this workgroup: its first DIST steps are already in flight and its step-0 fragments are in set A (nk is even)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    relax = (tm * BMx + BMx <= M) ? 2 : 0;          // full tile: every lane issued all its stores
+    vb += gridDim.x;
+    tm = tm_nx; tn = tn_nx;
+    sb = (sb + nk) & 3;
     }
 }
 
@@ -532,10 +614,29 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         static bool attr_done[16] = {};
         const int ai = EPI * 4 + (out_f32 ? 2 : 0) + (half ? 1 : 0);
         if (!attr_done[ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[ai] = true; }
+        // persistent walk (one workgroup per CU) when a workgroup gets more than one tile; needs an even number of K-steps (the
+        // fragment register sets ping-pong in pairs) and at least DIST + 1 of them.  SC_GEMM_PERSIST=0 switches it off (A/B runs).
+        static int persist = -1, n_cu = 0;
+        if (persist < 0) {
+            const char* e = getenv("SC_GEMM_PERSIST"); persist = e ? atoi(e) : 1;
+            int dev = 0; hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        const int nt_all = tM * tN, nk2 = K / BK2;
+        // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
+        const bool pers = persist && !half && !out_f32 && nt_all > n_cu && (nk2 % 2 == 0) && nk2 >= 4 && nk2 <= 64 && a_grp == 0 &&
+                          (size_t)M * (size_t)lda * 2 < (1ull << 31) && (size_t)N * (size_t)K * 2 < (1ull << 31);
 #define SC_L256(F32, WRV)                                                                                                                 \
         hipLaunchKernelGGL((k_gemm256<EPI, F32, WRV>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
-                           (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel)
-        if (half) { if (out_f32) SC_L256(true, 1); else SC_L256(false, 1); }
+                           (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all)
+        if (pers) {
+            static bool pattr[8] = {};
+            if (!pattr[EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm256<EPI, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); pattr[EPI] = true; }
+            hipLaunchKernelGGL((k_gemm256<EPI, false, 2, true>), dim3((unsigned)n_cu), block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W,
+                               (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all);
+        }
+        else if (half) { if (out_f32) SC_L256(true, 1); else SC_L256(false, 1); }
         else { if (out_f32) SC_L256(true, 2); else SC_L256(false, 2); }
 #undef SC_L256
         SC_CHECK_LAUNCH("sc_gemm_f16");

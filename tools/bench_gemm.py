@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from streamchat_amd import ops
 
-shapes = [(64 * 577, 3072, 1024, "vit.qkv"), (64 * 577, 1024, 1024, "vit.o"), (64 * 577, 4096, 1024, "vit.fc1"), (64 * 577, 1024, 4096, "vit.fc2"),
+shapes = [(56 * 577, 3072, 1024, "vit56.qkv"), (56 * 577, 1024, 1024, "vit56.o"), (56 * 577, 4096, 1024, "vit56.fc1"), (56 * 577, 1024, 4096, "vit56.fc2"),
+          (48994, 3584, 3584, "llm49k.q"), (48994, 3584, 18944, "llm49k.down"),
+          (64 * 577, 3072, 1024, "vit.qkv"), (64 * 577, 1024, 1024, "vit.o"), (64 * 577, 4096, 1024, "vit.fc1"), (64 * 577, 1024, 4096, "vit.fc2"),
           (64 * 576, 3584, 3584, "proj.2"), (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"), (26112, 18944, 3584, "llm.gate")]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[3] in sys.argv[1:]]
