@@ -25,6 +25,7 @@ from streamchat_amd import dist as DD, llm as LM, ops, streaming as S, synthetic
 from streamchat_amd.memory_bank.memory_retrieval import local_doc_qa as Q   # noqa: E402
 
 FRAMES = 1024
+MICRO_BATCH = int(os.environ.get("SC_MICRO_BATCH", "512"))     # frames per ViT pass: 512 x 577 rows = 1154 whole 256-row GEMM tiles, 6.6 GB of activations
 MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)   # inference_streamchat_v0.3.sh:12-19
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
@@ -51,7 +52,7 @@ class Pipeline:
         self.cfg = cfg
         self.sd_vit = V.random_clip_state_dict(cfg, seed=0, device=device)
         self.sd_proj = V.random_projector_state_dict(1024, 3584, seed=1, device=device)
-        self.enc = V.FrameEncoder(V.CLIPVisionTower(self.sd_vit, cfg, device=device), V.MMProjector(self.sd_proj, device=device), micro_batch=56)
+        self.enc = V.FrameEncoder(V.CLIPVisionTower(self.sd_vit, cfg, device=device), V.MMProjector(self.sd_proj, device=device), micro_batch=MICRO_BATCH)
         self.frames = torch.from_numpy(synthetic.frame_stream(n_frames, seed=seed)).to(device)        # resident in HBM
         self.feats = torch.empty((n_frames, cfg.num_patches, 3584), dtype=torch.float16, device=device)
         self.device = device
@@ -282,7 +283,7 @@ def main():
                                     "memory update (chunk 40, K 5, interval 10: one k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval"
                                     + (", LongVA-7B (Qwen2-7B shape) prefill of the retrieved context + first token" if full else ""),
                            context_tokens=pipe.last.get("context"),
-                           frames_per_gpu=a.frames, micro_batch=56, parallelism=f"dp{world}", weights="random-init"),
+                           frames_per_gpu=a.frames, micro_batch=MICRO_BATCH, parallelism=f"dp{world}", weights="random-init"),
                roofline=roof, stages=stages)
     if full and a.decode_tokens > 0 and world == 1:
         out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)

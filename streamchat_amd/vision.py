@@ -151,7 +151,7 @@ class MMProjector:
 class FrameEncoder:
     """`encode_images` of the reference (llava_arch.py:179-184): vision tower -> projector -> identity resampler."""
 
-    def __init__(self, tower: CLIPVisionTower, projector: MMProjector, micro_batch=56):
+    def __init__(self, tower: CLIPVisionTower, projector: MMProjector, micro_batch=512):
         self.tower, self.projector, self.micro_batch = tower, projector, micro_batch
 
     def _run(self, n_total, fill_patches, out):
