@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
 #ifndef SC_GEMM_SETPRIO
 #define SC_GEMM_SETPRIO 0     // s_setprio(1) around the MFMA clusters
 #endif
+#ifndef SC_GEMM_NS
+#define SC_GEMM_NS 4          // LDS ring slots of the 256x256 kernel (5 x 32 KiB = the whole 160 KiB LDS)
+#endif
 #ifndef SC_GEMM_MPL
 #define SC_GEMM_MPL 1         // MFMAs per interleaved load in the second cluster
 #endif
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
                                                          int a_grp_stride, int a_grp_off, int GM, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = WR * 256;                    // threads
-    constexpr int NS = WR == 2 ? 4 : 3;             // ring slots
+    constexpr int NS = WR == 2 ? SC_GEMM_NS : 3;    // ring slots
     constexpr int DIST = NS - 1;                    // DMA issue distance in K-steps
     constexpr int BMx = 128 * WR;
     constexpr int AH = BMx * BK2 * 2;               // A bytes per stage
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     const int nk = K / BK2;
     int sb = 0;                                     // ring slot of K-step 0 of the current tile (PERSIST: the ring runs on across tiles)
     bool has_next = false;
-    auto slot_of = [&](int ks) { return NS == 4 ? ((sb + ks) & 3) : (ks % 3); };
+    auto slot_of = [&](int ks) { return NS == 4 ? ((sb + ks) & 3) : ((sb + ks) % NS); };
     auto issue_w = [&](int ks) {
         char* base = smem + slot_of(ks) * STG + AH;
         if (PERSIST) {
@@ -301,8 +304,8 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     // epilogue's 16 (SwiGLU: 8) global stores, which share vmcnt on gfx9 - allow those stores (and the one younger DMA step) to stay
     // in flight, otherwise the wave stalls until its C tile has reached memory and the stores never overlap the next tile's MFMAs.
     auto wait_after_epilogue = [&]() {
-        if (EPI == SC_EPI_SWIGLU) { if (GW == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-        else { if (GW == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }
+        constexpr int CNT = (EPI == SC_EPI_SWIGLU ? 8 : 16) + (DIST - 2) * (2 + GW);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
     };
     int relax = 0;                                  // K-steps left that may use it (0 after an edge tile: fewer stores were issued)
 
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     issue_w(0); issue_a(0);
     if (nk > 1) { issue_w(1); issue_a(1); }
     if (DIST > 2 && nk > 2) { issue_w(2); issue_a(2); }
+    if (DIST > 3 && nk > 3) { issue_w(3); issue_a(3); }
     wait_steps((nk < DIST ? nk : DIST) - 1);
     __builtin_amdgcn_s_barrier();
     // fragment sets A / B ping-pong between consecutive K-steps (no register copies)
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
     relax = (tm * BMx + BMx <= M) ? 2 : 0;          // full tile: every lane issued all its stores
     vb += gridDim.x;
     tm = tm_nx; tn = tn_nx;
-    sb = (sb + nk) & 3;
+    sb = (sb + nk) % NS;
     }
 }
 
@@ -608,7 +612,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         const int bm = half ? 128 : 256;
         const int tM = (M + bm - 1) / bm, tN = N / BN2;
         const dim3 grid2((unsigned)(tM * tN)), block2(half ? 256 : 512);
-        const size_t lds2 = half ? 3 * (128 * BK2 * 2 + HALF2) : 4 * STAGE2;
+        const size_t lds2 = half ? 3 * (128 * BK2 * 2 + HALF2) : SC_GEMM_NS * STAGE2;
         const void* fn = half ? (out_f32 ? (const void*)k_gemm256<EPI, true, 1> : (const void*)k_gemm256<EPI, false, 1>)
                               : (out_f32 ? (const void*)k_gemm256<EPI, true, 2> : (const void*)k_gemm256<EPI, false, 2>);
         static bool attr_done[16] = {};
