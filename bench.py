@@ -263,7 +263,7 @@ def main():
     n, ms, work = prof.get("k_gemm", (0, 0.0, 0.0))
     traffic = None
     try:        # HBM bytes per launch from the committed PMC passes of this same command (profiles/, see its `correction` note)
-        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_gemm256"]["hbm_bytes_per_launch"])
+        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_gemm_all"]["hbm_bytes_per_launch"])
     except Exception:
         pass
     roof = dict(bound="mfma", kernel="k_gemm256 (+k_gemm128 for M<1024 or N%256)", launches=n, avg_ms=round(ms / max(n, 1), 5),
