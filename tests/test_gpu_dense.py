@@ -207,3 +207,41 @@ def test_gemm_skinny_rows(M, N, K, epi):
     ref = z * torch.sigmoid(1.702 * z) if epi == "quick_gelu" else (torch.nn.functional.gelu(z) if epi == "gelu" else z)
     torch.testing.assert_close(ops.gemm(a, w, b, r, epi).float(), ref + r.float(), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(ops.gemm(a, w, b, None, epi, out_f32=True), ref, rtol=1e-3, atol=1e-3)
+
+
+def test_attention_full_size_llm_prefill_rows_vs_torch():
+    """BASELINE C3 size: causal GQA 28/4 heads x 128 over 49 152 tokens (the LongVA-7B prefill shape).  Size-independent checks:
+    (1) V = 1 gives exactly-normalised rows (softmax weights sum to one); (2) 24 probe rows spread over the sequence (first / last
+    rows of blocks, the final row) against a per-row fp32 torch softmax over all their keys."""
+    S, Hq, Hkv, Dh = 49152, 28, 4, 128
+    g = torch.Generator(device="cuda").manual_seed(49)
+    q = torch.randn(1, S, Hq * Dh, device="cuda", generator=g).half()
+    k = torch.randn(1, S, Hkv * Dh, device="cuda", generator=g).half()
+    v = torch.randn(1, S, Hkv * Dh, device="cuda", generator=g).half()
+    scale = Dh ** -0.5
+    out = ops.attention(q, k, v, Hq, Hkv, Dh, scale, True)
+    rows = [0, 1, 63, 64, 191, 192, 193, 4095, 4096, 20000, 24575, 24576, 30001, 40000, 48959, 48960, 48961, 49000, 49087, 49088, 49150, 49151, 777, 12345]
+    for h in (0, 6, 7, 27):
+        kh, vh = k[0, :, (h // 7) * Dh:(h // 7 + 1) * Dh].float(), v[0, :, (h // 7) * Dh:(h // 7 + 1) * Dh].float()
+        for r in rows:
+            s = (q[0, r, h * Dh:(h + 1) * Dh].float() @ kh[: r + 1].t()) * scale
+            ref = torch.softmax(s, -1) @ vh[: r + 1]
+            torch.testing.assert_close(out[0, r, h * Dh:(h + 1) * Dh].float(), ref, rtol=3e-3, atol=3e-3)
+    ones = ops.attention(q, k, torch.ones_like(v), Hq, Hkv, Dh, scale, True)
+    assert (ones.float() - 1.0).abs().max().item() < 2e-3
+
+
+def test_gemm_full_size_llm_rows_vs_torch():
+    """BASELINE C3 size: the 48 994-row Qwen2-7B projections (q: 3584 -> 3584, down: 18944 -> 3584, gate_up SwiGLU: 3584 -> 2 x 18944);
+    128 probe rows (incl. the ragged last tile) against fp32 torch."""
+    M = 48994
+    rows = torch.cat([torch.arange(0, 32), torch.arange(24500, 24532), torch.arange(48896, 48928), torch.arange(M - 32, M)]).cuda()
+    for (N, K, epi) in [(3584, 3584, "none"), (3584, 18944, "none"), (37888, 3584, "swiglu")]:
+        a, w = _rand((M, K), 41), _rand((N, K), 42, K ** -0.5)
+        out = ops.gemm(a, w, None, None, epi)
+        z = a[rows].float() @ w.float().t()
+        if epi == "swiglu":
+            q4 = z.view(rows.numel(), N // 4, 2, 2)
+            z = (torch.nn.functional.silu(q4[:, :, 0]) * q4[:, :, 1]).reshape(rows.numel(), N // 2)
+        torch.testing.assert_close(out[rows].float(), z, rtol=2e-3, atol=2e-3)
+        del a, w, out
