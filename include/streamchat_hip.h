@@ -160,6 +160,10 @@ int sc_bert_embed_ln_f16(const int32_t* ids, const void* word, const void* pos, 
                          int vocab, sc_stream_t stream);
 int sc_pool_f16(const void* hidden, const int32_t* len, float* out, int B, int L, int H, int mode,
                 int normalize, sc_stream_t stream);
+/* Spatial average pooling of ViT token maps (reference utiles.py:264-289 compress_spatial_features -> F.avg_pool2d, --compress_rate):
+ * in [B, P*P, D] fp16 (row-major P x P token grid), out [B, g*g, D] fp16 with g = P / r (floor: trailing rows / columns are dropped),
+ * out[b, y*g + x] = mean over the r x r window, accumulated in fp32.  D % 8 == 0. */
+int sc_avgpool_tokens_f16(const void* in, void* out, int B, int P, int D, int r, sc_stream_t stream);
 /* Fused softmax(Q K^T * scale [+ mask]) V, fp16 in/out, fp32 online softmax (flash-style, S x S never
  * materialised).  Token-major layouts with explicit row strides (so q/k/v may alias one fused QKV buffer):
  *   q   [B, Sq,  Hq,  Dh]  row stride ldq elements, head h at column h*Dh

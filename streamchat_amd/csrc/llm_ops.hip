@@ -79,6 +79,29 @@ __global__ __launch_bounds__(256) void k_rope_row(_Float16* __restrict__ x, int 
     *reinterpret_cast<sc_h4*>(base + half + i0) = ob;
 }
 
+
+// out[b, y*g + x, d0..d0+7] = mean of in[b, (y*r + dy)*P + (x*r + dx), d0..d0+7] over the r x r window (fp32 accumulation)
+__global__ void k_avgpool_tokens(const _Float16* __restrict__ in, _Float16* __restrict__ out, int P, int D, int r, int g, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one thread = 8 channels of one output token
+    if (i >= total) return;
+    const int dv = D / 8;
+    const int d0 = (int)(i % dv) * 8;
+    const long tok = i / dv;
+    const int x = (int)(tok % g), y = (int)((tok / g) % g);
+    const long b = tok / ((long)g * g);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < r; ++dy)
+        for (int dx = 0; dx < r; ++dx) {
+            const sc_h8 v = *reinterpret_cast<const sc_h8*>(in + ((b * P + (y * r + dy)) * P + (x * r + dx)) * (long)D + d0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    const float inv = 1.0f / (float)(r * r);
+    sc_h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(acc[e] * inv);
+    *reinterpret_cast<sc_h8*>(out + tok * (long)D + d0) = o;
+}
 }  // namespace
 
 extern "C" int sc_rope_row_f16(void* buf, int ld, const int32_t* row_index, int heads, int Dh, float theta, sc_stream_t stream) {
@@ -108,5 +131,16 @@ extern "C" int sc_rope_f16(void* x, int ld, const int32_t* positions, int pos0, 
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(k_rope, dim3(grid), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, ld, positions, pos0, rows, heads, Dh, log2f(theta));
     SC_CHECK_LAUNCH("sc_rope_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_avgpool_tokens_f16(const void* in, void* out, int B, int P, int D, int r, sc_stream_t stream) {
+    SC_REQUIRE(in && out, "sc_avgpool_tokens_f16: null pointer argument");
+    SC_REQUIRE(B > 0 && P > 0 && D > 0 && D % 8 == 0 && r >= 1 && r <= P, "sc_avgpool_tokens_f16: bad sizes (D %% 8 == 0, 1 <= r <= P)");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "sc_avgpool_tokens_f16: pointers must be 16-byte aligned");
+    const int g = P / r;
+    const long total = (long)B * g * g * (D / 8);
+    hipLaunchKernelGGL(k_avgpool_tokens, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, P, D, r, g, total);
+    SC_CHECK_LAUNCH("sc_avgpool_tokens_f16");
     return SC_OK;
 }

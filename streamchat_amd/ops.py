@@ -350,6 +350,23 @@ def gather_rows(ids, table, out=None):
     return out
 
 
+def avgpool_tokens(x, r: int):
+    """[B, P*P, D] fp16 ViT token maps -> [B, (P//r)**2, D]: r x r spatial mean (reference compress_spatial_features)."""
+    _require_cuda(x)
+    lib = _lib.load()
+    x = x.contiguous()
+    B, S, D = x.shape
+    P = int(round(S ** 0.5))
+    if P * P != S:
+        raise StreamChatHipError(f"avgpool_tokens: {S} tokens are not a square grid")
+    g = P // r
+    out = torch.empty((B, g * g, D), dtype=torch.float16, device=x.device)
+    from ctypes import c_void_p
+    with torch.cuda.device(x.device):
+        check(lib.sc_avgpool_tokens_f16(c_void_p(x.data_ptr()), c_void_p(out.data_ptr()), B, P, D, r, stream_ptr(x.device)), "sc_avgpool_tokens_f16")
+    return out
+
+
 def rope_(x, heads: int, Dh: int, theta: float, pos0: int = 0, positions=None):
     """in-place rotate-half RoPE on x [rows, >= heads*Dh] (row-strided view allowed)."""
     _require_cuda(x)

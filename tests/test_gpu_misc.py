@@ -106,3 +106,13 @@ def test_tree_search_matches_reference_golden():
         assert txt == case["path_text"]
         assert [float(f.flatten()[0]) for f in feats] == case["path_first_value"]
         assert [list(f.shape) for f in feats] == case["path_shapes"]
+
+
+@pytest.mark.parametrize("B,P,D,r", [(3, 24, 3584, 2), (2, 24, 64, 5), (1, 6, 16, 6), (2, 4, 8, 1)])
+def test_compress_spatial_features_matches_avg_pool2d(B, P, D, r):
+    """reference utiles.py:264-289: F.avg_pool2d over the P x P token grid (floor mode), fp32 accumulation, fp16 out."""
+    x = torch.randn(B, P * P, D, device="cuda").half()
+    out = U.compress_spatial_features(list(torch.split(x, 1)), r)
+    ref = torch.nn.functional.avg_pool2d(x.float().reshape(B, P, P, D).permute(0, 3, 1, 2), (r, r)).permute(0, 2, 3, 1).reshape(B, -1, D)
+    assert len(out) == B and out[0].shape == (1, (P // r) ** 2, D)
+    torch.testing.assert_close(torch.cat(out).float(), ref, rtol=1e-3, atol=1e-3)
