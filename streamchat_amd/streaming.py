@@ -37,14 +37,35 @@ def video_reader_thread_with_embedding(cap, total_frames, frame_rate, image_proc
     the GPU (`model.encode_frames_u8`), replacing the per-frame PIL -> numpy -> torch -> H2D float round trip of
     :503-516.  Returns the feature bank: a list of [1, 576, D] views into ONE contiguous tensor."""
     frame_indices = sample_frame_indices(total_frames, frame_rate, start, end, sample_rate, chunk_size, clamp)
-    frames = []
-    for current_frame_number in frame_indices:
+    if len(frame_indices) == 0:
+        return []
+    first = cap.read_rgb(frame_indices[0])
+    if first is None:
+        return []
+    if not isinstance(first, torch.Tensor) and hasattr(model, "frame_encoder") and torch.device(device).type == "cuda":
+        # host decoder (cv2): decode -> pinned staging -> H2D -> encode as a bounded, overlapped pipeline (streamchat_amd/ingest.py)
+        from .ingest import AsyncFrameIngest
+        enc = model.frame_encoder
+        tokens, d_out = enc.tower.cfg.num_patches + (0 if enc.tower.select_feature == "patch" else 1), enc.projector.d_out
+        bank = torch.empty((len(frame_indices), tokens, d_out), dtype=torch.float16, device=device)
+
+        def frames_iter():
+            yield first
+            for n in frame_indices[1:]:
+                fr = cap.read_rgb(n)
+                if fr is None:
+                    return
+                yield fr
+        ing = AsyncFrameIngest(enc.encode_frames_u8, tuple(first.shape), micro_batch=min(64, len(frame_indices)), depth=2, device=device)
+        with torch.no_grad():
+            bs = ing.run(frames_iter(), bank)
+        return [bank[i:i + 1] for i in range(bs)]
+    frames = [first]
+    for current_frame_number in frame_indices[1:]:
         fr = cap.read_rgb(current_frame_number)
         if fr is None:
             break
         frames.append(fr)
-    if not frames:
-        return []
     batch = frames[0].new_empty((len(frames),) + tuple(frames[0].shape)) if isinstance(frames[0], torch.Tensor) else None
     if batch is None:
         batch = torch.from_numpy(np.stack(frames))

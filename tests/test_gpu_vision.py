@@ -87,3 +87,28 @@ def test_async_ingest_equals_synchronous_encode():
     assert ing.run(iter(frames), bank) == 19 and ing.stats["micro_batches"] == 5
     torch.cuda.synchronize()
     assert torch.equal(bank, ref)
+
+
+def test_video_reader_host_frames_go_through_async_ingest_and_match_device_frames():
+    """reference inference_streaming_longva_v2.py:454-531 with a HOST decoder (numpy frames, as cv2 yields them): the reader uses the
+    overlapped ingest pipeline; the feature bank equals the one built from the same frames already on the device."""
+    from streamchat_amd import llm as LM, streaming as S
+    d, sd, sp, cfg = _tiny()
+    enc = V.FrameEncoder(V.CLIPVisionTower(sd, cfg), V.MMProjector(sp))
+    model = LM.LlavaQwenForCausalLM.__new__(LM.LlavaQwenForCausalLM)
+    model.frame_encoder, model.device = enc, torch.device("cuda")
+    frames = np.random.default_rng(9).integers(0, 256, (90, 56, 56, 3), dtype=np.uint8)
+
+    class HostCap:
+        def read_rgb(self, i):
+            return frames[i] if i < len(frames) else None
+
+    class DevCap:
+        def read_rgb(self, i):
+            return torch.from_numpy(frames[i]).cuda() if i < len(frames) else None
+    a = S.video_reader_thread_with_embedding(HostCap(), 90, 2, None, model, 0, 40, "cuda", 0.5, chunk_size=4)
+    b = S.video_reader_thread_with_embedding(DevCap(), 90, 2, None, model, 0, 40, "cuda", 0.5, chunk_size=4)
+    torch.cuda.synchronize()
+    assert len(a) == len(b) > 0 and a[0].shape == (1, 16, 256)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert a[1].data_ptr() - a[0].data_ptr() == a[0].numel() * 2                  # views into ONE contiguous bank

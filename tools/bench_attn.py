@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from streamchat_amd import ops
 
-cases = [("vit", 64, 577, 16, 16, 64, False), ("llm8k", 1, 8192, 28, 4, 128, True), ("llm26k", 1, 26112, 28, 4, 128, True)]
+cases = [("vit", 64, 577, 16, 16, 64, False), ("llm8k", 1, 8192, 28, 4, 128, True), ("llm26k", 1, 26112, 28, 4, 128, True),
+         ("full26k", 1, 26112, 28, 4, 128, False), ("llm49k", 1, 49152, 28, 4, 128, True), ("vit512", 512, 577, 16, 16, 64, False)]
 if len(sys.argv) > 1:
     cases = [c for c in cases if c[0] in sys.argv[1:]]
 for (name, B, S, Hq, Hkv, Dh, causal) in cases:
