@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llm", action="store_true", help="C2 workload: stop after retrieval (no 7B prefill)")
-    ap.add_argument("--decode-tokens", type=int, default=32, help="decode tokens measured AFTER the timed region (reported separately)")
+    ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
     return ap.parse_args()
@@ -286,7 +286,8 @@ def main():
                            frames_per_gpu=a.frames, micro_batch=MICRO_BATCH, parallelism=f"dp{world}", weights="random-init"),
                roofline=roof, stages=stages)
     if full and a.decode_tokens > 0 and world == 1:
-        out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)
+        out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)         # greedy, batch 1, after the timed region (512 tokens)
+        out["decode_tokens"] = a.decode_tokens
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames)
     print(json.dumps(out))
