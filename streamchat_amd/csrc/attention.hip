@@ -10,13 +10,14 @@
 // With v_mfma_f32_16x16x32_f16 the C/D layout is col = lane&15, row = (lane>>4)*4 + r, so the P values a lane
 // produced for its query column are exactly the B-operand k-slots it must feed to the second MFMA (the
 // k-slot <-> kv-row bijection is applied to the V rows the transpose read fetches).  Row max / row sum /
-// rescale factors are therefore per-lane scalars: no LDS round trip and no cross-lane traffic for P; only a
-// 2-step xor-shuffle for the row max across the 4 lane groups.
+// rescale factors are therefore per-lane scalars: no LDS round trip and no cross-lane traffic for P; the row max across the
+// 4 lane groups is two VALU row swaps (v_permlane16_swap / v_permlane32_swap).
 //
-// (A 3-slot ring with counted vmcnt and 8-wave blocks was measured: no gain — the kernel is VALU-bound in the softmax, PMC:
-// 8.6 VALU instructions per MFMA — so the simpler double buffer stays.)
-// Block = 4 waves x QB q-blocks of 16 queries; KV tiles of 64 rows double-buffered in LDS via 16-byte
-// global_load_lds; bank-conflict-free XOR swizzles are applied on the per-lane source address and on the reads.
+// Block = 4 waves x QB q-blocks of 16 queries (QB = 2; 3 for long Dh = 128 prefill); KV tiles of 64 rows double-buffered in
+// LDS by 16-byte buffer_load ... lds (the resource extent is the valid cache length: rows past kv_len arrive as zeros);
+// bank-conflict-free XOR swizzles on the per-lane source address and on the reads.  The KV loop is a general tile body plus a
+// steady-state loop with no mask, no row max and no O rescale (see the notes at the loop); what bounds it - LDS fragment
+// traffic and the SIMD issue port - is measured in tools/probes/ and summarised in DESIGN.md section 4.
 #include "sc_common.h"
 #include <type_traits>
 
