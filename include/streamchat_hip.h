@@ -34,7 +34,7 @@ typedef void* sc_stream_t;
 enum { SC_F16 = 0, SC_BF16 = 1, SC_F32 = 2 };
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC_ERR_UNSUPPORTED = -4 };
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2   /* 2: sc_attention_f16 batch strides, sc_avgpool_tokens_f16 */
 
 int sc_abi_version(void);
 const char* sc_last_error(void);

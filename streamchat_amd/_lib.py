@@ -16,6 +16,7 @@ class StreamChatHipError(RuntimeError):
 
 
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
+ABI_VERSION = 2            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),
@@ -64,8 +65,8 @@ def load():
             raise StreamChatHipError(f"libstreamchat_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sc_abi_version() != 1:
-        raise StreamChatHipError(f"ABI version mismatch: library {lib.sc_abi_version()}, binding 1")
+    if lib.sc_abi_version() != ABI_VERSION:
+        raise StreamChatHipError(f"ABI version mismatch: library {lib.sc_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 
