@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
     const _Float16* wp[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
-    for (int k = lane * 8; k < K; k += 512) {
+#pragma unroll 4
+    for (int k = lane * 8; k < K; k += 512) {                       // (unrolled: >= 4 weight loads in flight per lane at RPW = 1)
         sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
         if (gamma) {
             const sc_h8 gv = *reinterpret_cast<const sc_h8*>(gamma + k);
