@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const _Float16* __restrict__
 constexpr int BM2 = 256, BN2 = 256, BK2 = 32;
 constexpr int HALF2 = BM2 * BK2 * 2;            // 16 KiB per operand per stage
 constexpr int STAGE2 = 2 * HALF2;               // 32 KiB
-constexpr int NSTAGE2 = 4;
 
 __device__ __forceinline__ int swzF(int x) { return (0x78 >> (2 * (x & 3))) & 3; }
 
