@@ -60,6 +60,7 @@ def parse_args(argv=None):
     p.add_argument("--embedding_model_id", type=str, default=None, help="mxbai-colbert-large-v1 checkpoint (reference :703)")
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
     p.add_argument("--max_new_tokens", type=int, default=256)
+    p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
     p.add_argument("--memory_tree_dir", type=str, default=None,
                    help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
     return p.parse_args(argv)
@@ -178,7 +179,7 @@ def run_inference(args):
                 long_memory_tree, short_memory_buffer = S.updating_memory_buffer(
                     feature_bank, long_memory_tree, model, tokenizer, args.multi_modal_memory, short_window=args.short_window,
                     remember_window=args.remember_window, tau=args.tau, compress_rate=args.compress_rate, chunk_size=args.chunk_size,
-                    num_clusters=args.num_clusters, interval=args.interval)
+                    num_clusters=args.num_clusters, interval=args.interval, batch_captions=args.batch_captions)
             output = inference_thread_with_memory_and_dialogue_retrival_test(
                 long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
                 args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"])

@@ -96,7 +96,7 @@ def _captioning_ids(summarizer_model, summarizer_tokenzier):
 
 def updating_memory_buffer(buffer_cache, long_memory_tree, summarizer_model, summarizer_tokenzier, building_multi_modal_memory_tree,
                            short_window=20, remember_window=5, tau=5, compress_rate=1, chunk_size=30, num_clusters=5, interval=10,
-                           rng=None):
+                           rng=None, batch_captions=False):
     """Mirror of :267-378: short-term memory by forgetting-curve sampling over the last `short_window` frames,
     long-term memory by chunking the whole buffer and growing the caption tree (at most one k-means merge)."""
     captioning_input_ids = _captioning_ids(summarizer_model, summarizer_tokenzier)
@@ -115,7 +115,7 @@ def updating_memory_buffer(buffer_cache, long_memory_tree, summarizer_model, sum
                                   for c in chunk_feature_list]
     long_memory_tree = U.fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_clusters, interval, summarizer_model,
                                                                    captioning_input_ids, summarizer_tokenzier, chunk_feature_list,
-                                                                   long_memory_tree)
+                                                                   long_memory_tree, batch_captions=batch_captions)
     assert len(short_memory_buffer) > 0, "No memory ?"
     return long_memory_tree, short_memory_buffer
 

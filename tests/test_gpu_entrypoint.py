@@ -13,7 +13,7 @@ def test_run_inference_synthetic_tiny(tmp_path):
     args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(tmp_path / "mem"), "--save_file",
                          str(tmp_path / "out.json"), "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "1",
                          "--tiny", "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3",
-                         "--max_new_tokens", "4", "--multi_modal_memory", "--memory_tree_dir", str(tmp_path / "trees")])
+                         "--max_new_tokens", "4", "--multi_modal_memory", "--memory_tree_dir", str(tmp_path / "trees"), "--batch_captions"])
     E.run_inference(args)
     out = json.load(open(tmp_path / "out.json"))
     assert len(out) == 2 and all(set(r) == {"time", "question", "label", "predict", "class", "process_time"} for r in out)
