@@ -150,6 +150,10 @@ int sc_rope_f16(void* x, int ld, const int32_t* positions, int pos0, int rows, i
                 sc_stream_t stream);
 /* RoPE on ONE row of a [rows, ld] buffer; the row number (= token position) is read from device memory (graph-replayable). */
 int sc_rope_row_f16(void* buf, int ld, const int32_t* row_index, int heads, int Dh, float theta, sc_stream_t stream);
+/* Decode step: RoPE of the new query row q [q_heads*Dh] (position row_index[0]) and of the K part of cache row row_index[0]
+ * ([rows, ld] buffer, K = the first kv_heads*Dh columns) in one launch. */
+int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, const int32_t* row_index, int kv_heads, int Dh,
+                       float theta, sc_stream_t stream);
 /* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
  * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
  *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)

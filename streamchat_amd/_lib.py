@@ -40,6 +40,7 @@ SIGNATURES = {
     "sc_avgpool_tokens_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_rope_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "sc_rope_qk_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_rope_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_sim_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

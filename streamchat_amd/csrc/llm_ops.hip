@@ -80,6 +80,37 @@ __global__ __launch_bounds__(256) void k_rope_row(_Float16* __restrict__ x, int 
 }
 
 
+// decode step: RoPE of the new query row (position row_index[0]) and of the K part of cache row row_index[0] in ONE launch
+// (each of the two separate launches is ~4.5 us of pure latency inside the captured decode graph)
+__global__ __launch_bounds__(256) void k_rope_qk_row(_Float16* __restrict__ q, int q_heads, _Float16* __restrict__ cache, int ld,
+                                                     const int* __restrict__ row_index, int kv_heads, int Dh, float log2_theta) {
+    const int half = Dh / 2, per_q = q_heads * (half / 4), per_k = kv_heads * (half / 4);
+    int rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= per_q + per_k) return;
+    const int row = row_index[0];
+    _Float16* x = q;
+    if (rem >= per_q) { rem -= per_q; x = cache + (size_t)row * ld; }
+    const int h = rem / (half / 4), i0 = (rem - h * (half / 4)) * 4;
+    const float p = (float)row;
+    _Float16* base = x + h * Dh;
+    sc_h4 a = *reinterpret_cast<const sc_h4*>(base + i0);
+    sc_h4 b = *reinterpret_cast<const sc_h4*>(base + half + i0);
+    sc_h4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float inv_freq = exp2f(-log2_theta * (float)(2 * (i0 + e)) / (float)Dh);
+        float sn, cs;
+        sincosf(p * inv_freq, &sn, &cs);
+        const _Float16 c16 = (_Float16)cs, s16 = (_Float16)sn;
+        const _Float16 t1 = (_Float16)((float)a[e] * (float)c16), t2 = (_Float16)((float)b[e] * (float)s16);
+        const _Float16 t3 = (_Float16)((float)b[e] * (float)c16), t4 = (_Float16)((float)a[e] * (float)s16);
+        oa[e] = (_Float16)((float)t1 - (float)t2);
+        ob[e] = (_Float16)((float)t3 + (float)t4);
+    }
+    *reinterpret_cast<sc_h4*>(base + i0) = oa;
+    *reinterpret_cast<sc_h4*>(base + half + i0) = ob;
+}
+
 // out[b, y*g + x, d0..d0+7] = mean of in[b, (y*r + dy)*P + (x*r + dx), d0..d0+7] over the r x r window (fp32 accumulation)
 __global__ void k_avgpool_tokens(const _Float16* __restrict__ in, _Float16* __restrict__ out, int P, int D, int r, int g, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one thread = 8 channels of one output token
@@ -142,5 +173,16 @@ extern "C" int sc_avgpool_tokens_f16(const void* in, void* out, int B, int P, in
     const long total = (long)B * g * g * (D / 8);
     hipLaunchKernelGGL(k_avgpool_tokens, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, P, D, r, g, total);
     SC_CHECK_LAUNCH("sc_avgpool_tokens_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, const int32_t* row_index, int kv_heads, int Dh, float theta,
+                                  sc_stream_t stream) {
+    SC_REQUIRE(q && cache && row_index, "sc_rope_qk_row_f16: null pointer argument");
+    SC_REQUIRE(q_heads > 0 && kv_heads > 0 && Dh > 0 && Dh % 8 == 0 && ld >= kv_heads * Dh && ld % 4 == 0 && theta > 1.f, "sc_rope_qk_row_f16: bad sizes");
+    const int total = (q_heads + kv_heads) * (Dh / 8);
+    hipLaunchKernelGGL(k_rope_qk_row, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (_Float16*)q, q_heads, (_Float16*)cache, ld,
+                       row_index, kv_heads, Dh, log2f(theta));
+    SC_CHECK_LAUNCH("sc_rope_qk_row_f16");
     return SC_OK;
 }

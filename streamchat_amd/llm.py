@@ -239,8 +239,7 @@ class DecodeGraph:
         for l, L in enumerate(lm.L):
             q = ops.gemv(L["wq"], h, L["bq"], rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)
             ops.gemv(L["wkv"], h, L["bkv"], out=lm.cache[l], out_row=self.pos, rms_gamma=L["ln1"], rms_eps=c.eps)   # KV row `pos` of the cache
-            ops.rope_(q, c.heads, Dh, c.rope_theta, positions=self.pos)
-            ops.rope_row_(lm.cache[l], self.pos, c.kv_heads, Dh, c.rope_theta)
+            ops.rope_qk_row_(q, c.heads, lm.cache[l], self.pos, c.kv_heads, Dh, c.rope_theta)        # q and the new K row, one launch
             ck = lm.cache[l]
             qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
             att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,

@@ -400,6 +400,17 @@ def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f
     return out
 
 
+def rope_qk_row_(q, q_heads: int, cache, row_index, kv_heads: int, Dh: int, theta: float):
+    """decode step: in-place RoPE of the query row `q` [q_heads*Dh] and of the K part of cache row `row_index` (device int32) - one launch."""
+    _require_cuda(q, cache, row_index)
+    lib = _lib.load()
+    from ctypes import c_void_p
+    with torch.cuda.device(q.device):
+        check(lib.sc_rope_qk_row_f16(c_void_p(q.data_ptr()), q_heads, c_void_p(cache.data_ptr()), cache.stride(0), ptr(row_index), kv_heads, Dh,
+                                     c_float(theta), stream_ptr(q.device)), "sc_rope_qk_row_f16")
+    return q
+
+
 def rope_row_(buf, row_index, heads: int, Dh: int, theta: float):
     """in-place RoPE on ONE row of `buf` [rows, ld]; the row number (= the token position) is read from the device int32 tensor
     `row_index` — hipGraph-replayable KV-cache append."""
