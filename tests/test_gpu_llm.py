@@ -160,3 +160,32 @@ def test_batched_greedy_decode_equals_one_by_one():
     cut = dec2.generate(6, eos_token_id=eos)
     for got, ref in zip(cut, single):
         assert got == (ref[:ref.index(eos) + 1] if eos in ref else ref)
+
+
+def test_rope_qk_row_equals_separate_ropes():
+    """the fused decode RoPE (query row + K part of the cache row, one launch) is bit-identical to the two separate kernels"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn(1, 28 * 128, device="cuda", generator=g).half()
+    cache = torch.randn(300, 2 * 4 * 128, device="cuda", generator=g).half()
+    pos = torch.tensor([217], dtype=torch.int32, device="cuda")
+    q1, c1 = q.clone(), cache.clone()
+    ops.rope_(q1, 28, 128, 1e6, positions=pos)
+    ops.rope_row_(c1, pos, 4, 128, 1e6)
+    q2, c2 = q.clone(), cache.clone()
+    ops.rope_qk_row_(q2, 28, c2, pos, 4, 128, 1e6)
+    assert torch.equal(q1, q2) and torch.equal(c1, c2)
+    assert torch.equal(c2[:217], cache[:217]) and torch.equal(c2[218:], cache[218:]) and torch.equal(c2[217, 512:], cache[217, 512:])   # V part and other rows untouched
+
+
+def test_batched_sampling_is_reproducible_and_plausible():
+    """do_sample=True in the batched decoder: same default-generator seed -> same tokens (graph path); temperature -> 0 approaches greedy"""
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    lm = LM.Qwen2Model(sd, cfg, max_seq=64)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        outs.append(LM.BatchDecoder(lm, [emb, emb[:20]], max_new_tokens=6).generate(6, do_sample=True, temperature=0.8))
+    assert outs[0] == outs[1] and all(len(t) == 6 for t in outs[0])
+    cold = LM.BatchDecoder(lm, [emb, emb[:20]], max_new_tokens=6).generate(6, do_sample=True, temperature=1e-4)
+    assert cold == LM.BatchDecoder(lm, [emb, emb[:20]], max_new_tokens=6).generate(6)
