@@ -510,6 +510,196 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// v3 ("fat waves"): the same 256x256 tile and 4-slot LDS ring, but FOUR waves (2 x 2), each owning 128 x 128 of the tile:
+// 64 accumulator tiles per wave (256 accumulation registers: the compiler keeps them in AGPRs, one wave per SIMD with the whole
+// 512-register file), 16 fragment reads per 64 MFMAs.  LDS fragment traffic per MFMA drops from 0.375 KB (128x64 wave tiles)
+// to 0.25 KB, which is what the LDS-DMA writes of the ring compete with; K-steps are 64 MFMAs long, so the 16 fragment reads
+// and 8 DMA issues of the next steps hide under them with room to spare.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                     const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                     void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = (int)gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tilesM = nwg / tilesN;
+    const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
+    const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
+    const int tm = grp * GM + within % gm, tn = within / gm;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // LDS: two buffers of [A | W], each operand as two K-half planes of 256 rows x 64 B (K = 64 per iteration); within a plane the
+    // 16-byte chunk c of row r sits at r * 64 + ((c ^ swzF(r >> 2)) << 4) (conflict-free ds_read_b128 fragments, lane-linear DMA).
+    // One DMA instruction moves 64 rows x 64 B of one plane; the two planes of the same rows are issued back to back, so both
+    // halves of every 128-byte line of the operand are consumed while the line is in flight / in the L1 (fetching the halves a
+    // K-step apart, as with K = 32 stages, costs twice the L2 -> L1 line traffic).
+    constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB;
+    const int dr = tid >> 2, dc = (tid & 3) ^ swzF(tid >> 4);
+    const unsigned a_vo = ((unsigned)dr * (unsigned)lda + (unsigned)(dc * 8)) * 2u, w_vo = ((unsigned)dr * (unsigned)K + (unsigned)(dc * 8)) * 2u;
+    // buffer resources are rebased per tile (base = first row of the tile, extent = its valid rows), so operands of any size work
+    // with 32-bit offsets and rows past M / N read as zeros
+    const _Float16* At = A + (size_t)tm * (size_t)BM2 * (size_t)lda;
+    const _Float16* Wt = W + (size_t)tn * (size_t)BN2 * (size_t)K;
+    const int a_rows = (M - tm * BM2) < BM2 ? (M - tm * BM2) : BM2, w_rows = (N - tn * BN2) < BN2 ? (N - tn * BN2) : BN2;
+    const unsigned a_ext = (unsigned)a_rows * (unsigned)lda * 2u, w_ext = (unsigned)w_rows * (unsigned)K * 2u;
+    const unsigned a_rs = 64u * (unsigned)lda * 2u, w_rs = 64u * (unsigned)K * 2u;          // 64 rows per DMA round
+    const int nk = K >> 6;
+    const int rl = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    // fragment addresses: [K half h][buffer X]; + i * 1024 per 16-row tile
+    unsigned a_ad[2][2], b_ad[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const unsigned frag = (unsigned)(rl * 64 + ((g ^ swzF(rl >> 2)) << 4));
+            a_ad[h][X] = lds0 + (unsigned)(X * BUF + h * PL) + (unsigned)(wr * 128 * 64) + frag;
+            b_ad[h][X] = lds0 + (unsigned)(X * BUF + OPB + h * PL) + (unsigned)(wc * 128 * 64) + frag;
+        }
+
+    sc_f4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
+
+    // The main loop is laid out by hand: MFMAs (accumulators tied in place in AGPRs), fragment reads and waits are volatile asm
+    // in program order, because hipcc's allocator otherwise rotates the 256 accumulation registers through VGPRs every step.
+#define FAT_RD(dst, ad, I) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"((I) * 1024))
+#define FAT_MM(I, J, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(b[J]), "v"(a[I]))
+    // DMA round t (0..7: W, 8..15: A) of iteration k into buffer X; iterations past the end fetch nothing (extent 0 -> zeros), so
+    // every loop iteration is identical (no tail code: hipcc shuffles all 256 accumulators around any conditional tail)
+    auto dma = [&](int t, int X, int k) {
+        const unsigned ko = (unsigned)k * 128u + (unsigned)(t & 1) * 64u;          // K half = t & 1, row group = (t & 7) >> 1
+        const bool live = k < nk;
+        const int rg = (t & 7) >> 1, lo = (t & 1) * PL + (rg * 256 + wave * 64) * 16;
+        if (t < 8) lds_load16(Wt, live ? w_ext : 0u, smem + X * BUF + OPB + lo, w_vo, ko + (unsigned)rg * w_rs);
+        else lds_load16(At, live ? a_ext : 0u, smem + X * BUF + lo, a_vo, ko + (unsigned)rg * a_rs);
+    };
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dma(t, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dma(t, 1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    sc_h8 a0[8], b0[8], a1[8], b1[8];                           // fragment sets of the two K halves
+    FAT_RD(b0[0], b_ad[0][0], 0); FAT_RD(b0[1], b_ad[0][0], 1); FAT_RD(b0[2], b_ad[0][0], 2); FAT_RD(b0[3], b_ad[0][0], 3);
+    FAT_RD(b0[4], b_ad[0][0], 4); FAT_RD(b0[5], b_ad[0][0], 5); FAT_RD(b0[6], b_ad[0][0], 6); FAT_RD(b0[7], b_ad[0][0], 7);
+    FAT_RD(a0[0], a_ad[0][0], 0); FAT_RD(a0[1], a_ad[0][0], 1); FAT_RD(a0[2], a_ad[0][0], 2); FAT_RD(a0[3], a_ad[0][0], 3);
+    FAT_RD(a0[4], a_ad[0][0], 4); FAT_RD(a0[5], a_ad[0][0], 5); FAT_RD(a0[6], a_ad[0][0], 6); FAT_RD(a0[7], a_ad[0][0], 7);
+    // iteration k on buffer X, 128 MFMAs t = 0..127 (t < 64: K half 0 from a0/b0, then K half 1 from a1/b1):
+    //   t = 0..15   + the 16 fragment reads of K half 1                      | t = RB: all reads of buffer X are done -> barrier
+    //   t = RB..    + the 16 DMA rounds of iteration k + 2 into buffer X     | t = RC: iteration k + 1 has landed -> wait + barrier
+    //   t = RC..    + the 16 fragment reads of (k + 1, K half 0) from the other buffer (a0/b0 are free after t = 63)
+#ifndef FAT_RB
+#define FAT_RB 20
+#define FAT_RC 100
+#define FAT_DS 7
+#define FAT_RS 1
+#endif
+    constexpr int RB = FAT_RB, RC = FAT_RC, DS = FAT_DS, RS = FAT_RS;      // DS: MFMAs per DMA round, RS: MFMAs per fragment read
+    constexpr int DMA_BEFORE_RC = (RC - RB + DS - 1) / DS < 16 ? (RC - RB + DS - 1) / DS : 16;
+    static_assert(RB + 15 * DS < 128 && RC + 15 * RS < 128 && 15 * RS < RB, "schedule does not fit the iteration");
+    auto iter = [&](auto Xc, int k) {
+        constexpr int X = decltype(Xc)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hi = 0; hi < 16; ++hi)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = hi * 8 + j, i = hi & 7;
+            if (t == RB) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            if (t == RC) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory"); __builtin_amdgcn_s_barrier(); }
+            if (t < 64) FAT_MM(i, j, a0, b0); else FAT_MM(i, j, a1, b1);
+            if (t < 16 * RS && t % RS == 0) { const int u = (t / RS) & 7; if (t / RS < 8) FAT_RD(b1[u], b_ad[1][X], u); else FAT_RD(a1[u], a_ad[1][X], u); }
+            if (t >= RB && t < RB + 16 * DS && (t - RB) % DS == 0) dma((t - RB) / DS, X, k + 2);
+            if (t >= RC && t < RC + 16 * RS && (t - RC) % RS == 0) {
+                const int u = ((t - RC) / RS) & 7;
+                if ((t - RC) / RS < 8) FAT_RD(b0[u], b_ad[0][X ^ 1], u); else FAT_RD(a0[u], a_ad[0][X ^ 1], u);
+            }
+        }
+    };
+    for (int k = 0; k < nk; k += 2) {                           // nk is even (dispatch)
+        iter(std::integral_constant<int, 0>{}, k);
+        iter(std::integral_constant<int, 1>{}, k + 1);
+    }
+    // the asm MFMAs are invisible to the hazard recognizer: drain before reading acc.  vmcnt(0): the (zero-fill) DMA rounds of the
+    // last two iterations must not land in the LDS of the workgroup that follows this one on the CU.
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" : "+a"(acc[7][4]), "+a"(acc[7][5]), "+a"(acc[7][6]), "+a"(acc[7][7]) :: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef FAT_RD
+#undef FAT_MM
+
+    // ---- epilogue: as k_gemm256 (lane owns C[m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3]), 8 x 8 tiles per wave ----
+    const int m0 = tm * BM2 + wr * 128, n0 = tn * BN2 + wc * 128;
+    auto pack2 = [](float x, float y) -> unsigned { const sc_h2 h = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(unsigned, h); };
+    _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    if (EPI == SC_EPI_SWIGLU) {
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {                        // two groups of four 16-column tiles -> 32 output columns each
+            float bv[4][4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[nj][e] = bias ? (float)bias[n0 + (q4 * 4 + nj) * 16 + g * 4 + e] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = m0 + mi * 16 + rl;
+                unsigned d[4];
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const sc_f4 c = acc[mi][q4 * 4 + nj];
+                    const float g0 = c[0] + bv[nj][0], g1 = c[1] + bv[nj][1], u0 = c[2] + bv[nj][2], u1 = c[3] + bv[nj][3];
+                    d[nj] = pack2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+                }
+                const auto p0 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                const auto p1 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+                const auto q0 = __builtin_amdgcn_permlane32_swap(p0[0], p1[0], false, false);
+                const auto q1 = __builtin_amdgcn_permlane32_swap(p0[1], p1[1], false, false);
+                if (m < M) *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + (n0 >> 1) + q4 * 32 + g * 8) = u4v{q0[0], q1[0], q0[1], q1[1]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            float bv[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[h][e] = bias ? (float)bias[n0 + (2 * pr + h) * 16 + g * 4 + e] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = m0 + mi * 16 + rl;
+                const bool live = m < M;
+                unsigned lo[2], hi[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nj = 2 * pr + h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI);
+                    if (R && live) {
+                        const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n0 + nj * 16 + g * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                    }
+                    (h ? hi : lo)[0] = pack2(v[0], v[1]);
+                    (h ? hi : lo)[1] = pack2(v[2], v[3]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                if (live) *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + n0 + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8) = u4v{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // skinny M (<= 32 rows): batched decode / few-token projections.  HBM-bound: W is streamed exactly once, straight from global
 // memory into MFMA A-operand registers (every weight element is used once, so LDS staging would only add traffic); the few
 // activation rows are the B operand and come out of L2.  One workgroup = one strip of 16 W rows (= 16 output columns); its 4
@@ -628,6 +818,16 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         }
         const int nt_all = tM * tN, nk2 = K / BK2;
         // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
+        static int fat = -1;
+        if (fat < 0) { const char* e = getenv("SC_GEMM_FAT"); fat = e ? atoi(e) : 1; }
+        if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31)) {
+            static bool fattr[8] = {};
+            if (!fattr[EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm_fat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); fattr[EPI] = true; }
+            hipLaunchKernelGGL((k_gemm_fat<EPI>), grid2, dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel);
+            SC_CHECK_LAUNCH("sc_gemm_f16");
+            return SC_OK;
+        }
         const bool pers = persist && !half && !out_f32 && nt_all > n_cu && (nk2 % 2 == 0) && nk2 >= 4 && nk2 <= 64 && a_grp == 0 &&
                           (size_t)M * (size_t)lda * 2 < (1ull << 31) && (size_t)N * (size_t)K * 2 < (1ull << 31);
 #define SC_L256(F32, WRV)                                                                                                                 \
