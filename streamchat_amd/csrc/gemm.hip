@@ -26,7 +26,7 @@ constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 
 __device__ __forceinline__ float epi_apply(float x, int epi) {
-    if (epi == SC_EPI_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    if (epi == SC_EPI_QUICK_GELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     if (epi == SC_EPI_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return x;
 }
@@ -187,6 +187,14 @@ __device__ __forceinline__ int swzF(int x) { return (0x78 >> (2 * (x & 3))) & 3;
 // 16-byte LDS-DMA through a raw buffer resource (base, extent in bytes): lane address = base + voff + soff, destination = the
 // wave-uniform LDS pointer + lane * 16; lanes past the extent write zeros.  (A free function: an opaque __amdgpu_buffer_rsrc_t
 // inside a lambda of the kernel silently drops the kernel's host stub.)
+// buffer resource from values the compiler may have computed on the vector ALU (scalar registers are scarce in the persistent GEMM):
+// force base and extent into SGPRs so that buffer instructions need no waterfall loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, int extent) {
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(extent), 0x00020000);
+}
+
 __device__ __forceinline__ void lds_load16(const void* base, unsigned extent, char* lds, unsigned voff, unsigned soff) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)extent, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
@@ -516,18 +524,23 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 // to 0.25 KB, which is what the LDS-DMA writes of the ring compete with; K-steps are 64 MFMAs long, so the 16 fragment reads
 // and 8 DMA issues of the next steps hide under them with room to spare.
 // ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
-                                                     void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM) {
+                                                     void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nwg = (int)gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tilesM = nwg / tilesN;
-    const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
-    const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
-    const int tm = grp * GM + within % gm, tn = within / gm;
+    // virtual block vb -> tile (same XCD-aware grouped order for the one-tile-per-workgroup launch and the persistent walk
+    // vb = blockIdx.x, + gridDim.x, ...; gridDim.x is a multiple of 8 there, so a workgroup stays on the XCD slice of its tiles)
+    const int tilesM = ntiles / tilesN;
+    auto tile_of = [&](int vb, int& tm_, int& tn_) {
+        const int xcd = vb & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        const int grp = swz / (GM * tilesN), within = swz - grp * (GM * tilesN);
+        const int gm = (tilesM - grp * GM) < GM ? (tilesM - grp * GM) : GM;
+        tm_ = grp * GM + within % gm; tn_ = within / gm;
+    };
+    int vb = blockIdx.x, tm, tn;
+    tile_of(vb, tm, tn);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -539,14 +552,26 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // K-step apart, as with K = 32 stages, costs twice the L2 -> L1 line traffic).
     constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB;
     const int dr = tid >> 2, dc = (tid & 3) ^ swzF(tid >> 4);
-    const unsigned a_vo = ((unsigned)dr * (unsigned)lda + (unsigned)(dc * 8)) * 2u, w_vo = ((unsigned)dr * (unsigned)K + (unsigned)(dc * 8)) * 2u;
     // buffer resources are rebased per tile (base = first row of the tile, extent = its valid rows), so operands of any size work
-    // with 32-bit offsets and rows past M / N read as zeros
-    const _Float16* At = A + (size_t)tm * (size_t)BM2 * (size_t)lda;
-    const _Float16* Wt = W + (size_t)tn * (size_t)BN2 * (size_t)K;
-    const int a_rows = (M - tm * BM2) < BM2 ? (M - tm * BM2) : BM2, w_rows = (N - tn * BN2) < BN2 ? (N - tn * BN2) : BN2;
-    const unsigned a_ext = (unsigned)a_rows * (unsigned)lda * 2u, w_ext = (unsigned)w_rows * (unsigned)K * 2u;
-    const unsigned a_rs = 64u * (unsigned)lda * 2u, w_rs = 64u * (unsigned)K * 2u;          // 64 rows per DMA round
+    // with 32-bit offsets and rows past M / N read as zeros; the four 64-row groups of a DMA round set get their own lane offsets
+    unsigned a_vo[4], w_vo[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        a_vo[rg] = ((unsigned)(rg * 64 + dr) * (unsigned)lda + (unsigned)(dc * 8)) * 2u;
+        w_vo[rg] = ((unsigned)(rg * 64 + dr) * (unsigned)K + (unsigned)(dc * 8)) * 2u;
+    }
+    const _Float16 *At, *Wt, *At_nx = A, *Wt_nx = W;
+    unsigned a_ext, w_ext, a_ext_nx = 0, w_ext_nx = 0;
+    auto tile_src = [&](int tm_, int tn_, const _Float16*& At_, const _Float16*& Wt_, unsigned& ae, unsigned& we) {
+        At_ = A + (size_t)tm_ * (size_t)BM2 * (size_t)lda;
+        Wt_ = W + (size_t)tn_ * (size_t)BN2 * (size_t)K;
+        const int ar = (M - tm_ * BM2) < BM2 ? (M - tm_ * BM2) : BM2, wrw = (N - tn_ * BN2) < BN2 ? (N - tn_ * BN2) : BN2;
+        ae = (unsigned)ar * (unsigned)lda * 2u; we = (unsigned)wrw * (unsigned)K * 2u;
+    };
+    tile_src(tm, tn, At, Wt, a_ext, w_ext);
+    int tm_nx = 0, tn_nx = 0;
+    bool has_nx = PERSIST && vb + (int)gridDim.x < ntiles;
+    if (has_nx) { tile_of(vb + (int)gridDim.x, tm_nx, tn_nx); tile_src(tm_nx, tn_nx, At_nx, Wt_nx, a_ext_nx, w_ext_nx); }
     const int nk = K >> 6;
     const int rl = lane & 15, g = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
@@ -562,23 +587,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         }
 
     sc_f4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
 
     // The main loop is laid out by hand: MFMAs (accumulators tied in place in AGPRs), fragment reads and waits are volatile asm
     // in program order, because hipcc's allocator otherwise rotates the 256 accumulation registers through VGPRs every step.
 #define FAT_RD(dst, ad, I) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"((I) * 1024))
 #define FAT_MM(I, J, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(b[J]), "v"(a[I]))
-    // DMA round t (0..7: W, 8..15: A) of iteration k into buffer X; iterations past the end fetch nothing (extent 0 -> zeros), so
-    // every loop iteration is identical (no tail code: hipcc shuffles all 256 accumulators around any conditional tail)
+    // DMA round t (0..7: W, 8..15: A) of iteration k into buffer X.  Iterations past the end of the tile fetch the first
+    // iterations of the workgroup's NEXT tile (persistent walk: its data lands while this tile's epilogue stores), or nothing
+    // (extent 0 -> zeros) after the last tile: every loop iteration is identical (no tail code: hipcc shuffles all 256
+    // accumulators around any conditional tail).
     auto dma = [&](int t, int X, int k) {
-        const unsigned ko = (unsigned)k * 128u + (unsigned)(t & 1) * 64u;          // K half = t & 1, row group = (t & 7) >> 1
-        const bool live = k < nk;
-        const int rg = (t & 7) >> 1, lo = (t & 1) * PL + (rg * 256 + wave * 64) * 16;
-        if (t < 8) lds_load16(Wt, live ? w_ext : 0u, smem + X * BUF + OPB + lo, w_vo, ko + (unsigned)rg * w_rs);
-        else lds_load16(At, live ? a_ext : 0u, smem + X * BUF + lo, a_vo, ko + (unsigned)rg * a_rs);
+        const bool nx = k >= nk;
+        const unsigned ko = (unsigned)(nx ? k - nk : k) * 128u + (unsigned)(t & 1) * 64u;          // K half = t & 1
+        const int rg = (t & 7) >> 1, lo = (t & 1) * PL + (rg * 256 + wave * 64) * 16;           // row group = (t & 7) >> 1
+        if (t < 8) lds_load16(nx ? Wt_nx : Wt, nx ? w_ext_nx : w_ext, smem + X * BUF + OPB + lo, w_vo[rg], ko);
+        else lds_load16(nx ? At_nx : At, nx ? a_ext_nx : a_ext, smem + X * BUF + lo, a_vo[rg], ko);
     };
 #pragma unroll
     for (int t = 0; t < 16; ++t) dma(t, 0, 0);
@@ -606,6 +629,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     static_assert(RB + 15 * DS < 128 && RC + 15 * RS < 128 && 15 * RS < RB, "schedule does not fit the iteration");
     auto iter = [&](auto Xc, int k) {
         constexpr int X = decltype(Xc)::value;
+        const int fin = (k + 1 >= nk) ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int hi = 0; hi < 16; ++hi)
@@ -614,7 +638,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
             const int t = hi * 8 + j, i = hi & 7;
             if (t == RB) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             if (t == RC) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory"); __builtin_amdgcn_s_barrier(); }
-            if (t < 64) FAT_MM(i, j, a0, b0); else FAT_MM(i, j, a1, b1);
+            if (t < 64) FAT_MM(i, j, a0, b0);
+            else if (X == 0 || t < 127) FAT_MM(i, j, a1, b1);
+            else    // last MFMA of an iteration pair: after the tile's final one, drain the MFMA pipe INSIDE the same asm statement
+                    // (the asm MFMAs are invisible to the hazard recognizer, and the compiler is free to put accumulator moves
+                    // right behind any separate drain statement)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tv_cmp_ne_u32 vcc, 0, %3\n\ts_cbranch_vccz .Lfat_nodrain%=\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n"
+                             ".Lfat_nodrain%=:" : "+a"(acc[7][7]) : "v"(b1[7]), "v"(a1[7]), "v"(fin) : "vcc");
             if (t < 16 * RS && t % RS == 0) { const int u = (t / RS) & 7; if (t / RS < 8) FAT_RD(b1[u], b_ad[1][X], u); else FAT_RD(a1[u], a_ad[1][X], u); }
             if (t >= RB && t < RB + 16 * DS && (t - RB) % DS == 0) dma((t - RB) / DS, X, k + 2);
             if (t >= RC && t < RC + 16 * RS && (t - RC) % RS == 0) {
@@ -623,80 +653,122 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
             }
         }
     };
+    for (;;) {                                                  // tiles of this workgroup (one unless PERSIST)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nk; k += 2) {                           // nk is even (dispatch)
         iter(std::integral_constant<int, 0>{}, k);
         iter(std::integral_constant<int, 1>{}, k + 1);
     }
-    // the asm MFMAs are invisible to the hazard recognizer: drain before reading acc.  vmcnt(0): the (zero-fill) DMA rounds of the
-    // last two iterations must not land in the LDS of the workgroup that follows this one on the CU.
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" : "+a"(acc[7][4]), "+a"(acc[7][5]), "+a"(acc[7][6]), "+a"(acc[7][7]) :: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef FAT_RD
-#undef FAT_MM
+    // the asm MFMAs are invisible to the hazard recognizer: drain before reading acc
+    // after the last tile: the (zero-fill) DMA rounds of the last two iterations must not land in the LDS of the workgroup that
+    // follows this one on the CU
+    if (!has_nx) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: as k_gemm256 (lane owns C[m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3]), 8 x 8 tiles per wave ----
-    const int m0 = tm * BM2 + wr * 128, n0 = tn * BN2 + wc * 128;
+    // ---- epilogue: lane owns C[m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3], 8 x 8 tiles per wave.  Bias, residual and the stores
+    // go through per-wave buffer resources (null operand / rows >= M -> extent says out of range -> reads 0 / store dropped), so
+    // the code is branch-free and the residual loads of a whole column pair are in flight together. ----
+    {
+    const int m0 = __builtin_amdgcn_readfirstlane(tm * BM2 + wr * 128), n0 = __builtin_amdgcn_readfirstlane(tn * BN2 + wc * 128);
+    const int rv = (M - m0) < 0 ? 0 : ((M - m0) > 128 ? 128 : (M - m0));                  // valid rows of this wave's sub-tile
+    // The range check of a buffer access covers the VGPR offset only (not the scalar offset), so the row part of every address
+    // stays in the VGPR offset and only column steps go to the scalar one.  The row steps are made opaque per tile: otherwise
+    // hipcc precomputes all 64 row offsets outside the tile loop and spills them.
+    int rstep_c = 32 * ldc, rstep_r = 32 * ldr;
+    asm volatile("" : "+v"(rstep_c), "+v"(rstep_r));
     auto pack2 = [](float x, float y) -> unsigned { const sc_h2 h = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(unsigned, h); };
+    auto h4f = [](sc_u2 v, float (&f)[4]) {
+        const unsigned x0 = v.x, x1 = v.y;                      // (bit_cast straight from v[1] miscompiles to element 0 with this hipcc)
+        const sc_h2 lo = __builtin_bit_cast(sc_h2, x0), hi = __builtin_bit_cast(sc_h2, x1);
+        f[0] = (float)lo[0]; f[1] = (float)lo[1]; f[2] = (float)hi[0]; f[3] = (float)hi[1];
+    };
     _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_b = uniform_rsrc(bias ? bias + n0 : W, bias ? 256 : 0);
     if (EPI == SC_EPI_SWIGLU) {
+        const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + (n0 >> 1), rv * ldc * 2);
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {                        // two groups of four 16-column tiles -> 32 output columns each
             float bv[4][4];
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[nj][e] = bias ? (float)bias[n0 + (q4 * 4 + nj) * 16 + g * 4 + e] : 0.f;
+            for (int nj = 0; nj < 4; ++nj) h4f(__builtin_amdgcn_raw_buffer_load_b64(rs_b, g * 8, (q4 * 4 + nj) * 32, 0), bv[nj]);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                const int m = m0 + mi * 16 + rl;
                 unsigned d[4];
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj) {
                     const sc_f4 c = acc[mi][q4 * 4 + nj];
                     const float g0 = c[0] + bv[nj][0], g1 = c[1] + bv[nj][1], u0 = c[2] + bv[nj][2], u1 = c[3] + bv[nj][3];
-                    d[nj] = pack2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+                    d[nj] = pack2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
                 }
                 const auto p0 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
                 const auto p1 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
                 const auto q0 = __builtin_amdgcn_permlane32_swap(p0[0], p1[0], false, false);
                 const auto q1 = __builtin_amdgcn_permlane32_swap(p0[1], p1[1], false, false);
-                if (m < M) *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + (n0 >> 1) + q4 * 32 + g * 8) = u4v{q0[0], q1[0], q0[1], q1[1]};
+                unsigned w0 = q0[0], w1 = q1[0], w2 = q0[1], w3 = q1[1];
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl * ldc + g * 8) * 2 + mi * rstep_c, q4 * 64, 0);
+                asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));      // see the note at the other store below
             }
         }
     } else {
+        const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
+        const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             float bv[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) h4f(__builtin_amdgcn_raw_buffer_load_b64(rs_b, g * 8, (2 * pr + h) * 32, 0), bv[h]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[h][e] = bias ? (float)bias[n0 + (2 * pr + h) * 16 + g * 4 + e] : 0.f;
+            for (int mh = 0; mh < 2; ++mh) {                    // residual loads of four row tiles in flight together
+                sc_u2 rr[4][2];
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = m0 + mi * 16 + rl;
-                const bool live = m < M;
-                unsigned lo[2], hi[2];
+                for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int nj = 2 * pr + h;
-                    float v[4];
+                    for (int h = 0; h < 2; ++h)
+                        rr[mq][h] = R ? __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rl * ldr + g * 4) * 2 + (mh * 4 + mq) * rstep_r, (2 * pr + h) * 32, 0) : sc_u2{0u, 0u};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI);
-                    if (R && live) {
-                        const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n0 + nj * 16 + g * 4);
+                for (int mq = 0; mq < 4; ++mq) {
+                    const int mi = mh * 4 + mq;
+                    unsigned lo[2], hi[2];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                    for (int h = 0; h < 2; ++h) {
+                        const int nj = 2 * pr + h;
+                        float v[4], r4[4];
+                        h4f(rr[mq][h], r4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI) + r4[e];
+                        (h ? hi : lo)[0] = pack2(v[0], v[1]);
+                        (h ? hi : lo)[1] = pack2(v[2], v[3]);
                     }
-                    (h ? hi : lo)[0] = pack2(v[0], v[1]);
-                    (h ? hi : lo)[1] = pack2(v[2], v[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                    // gfx950: a VALU write to the data registers of a 16-byte buffer store in the very next instruction corrupts the
+                    // stored value (seen as garbage in lanes 12..15 of each row of 16; profiles/r01_run161) and hipcc does not guard
+                    // it: the asm keeps the four registers allocated past the store and puts wait states before any reuse
+                    unsigned w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];
+                    __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl * ldc + (g & 1) * 16 + (g >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32, 0);
+                    asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
                 }
-                const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-                if (live) *reinterpret_cast<u4v*>(Ch + (size_t)m * (size_t)ldc + n0 + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8) = u4v{s0[0], s1[0], s0[1], s1[1]};
             }
         }
     }
+    }
+    if (!has_nx) break;
+    vb += (int)gridDim.x;
+    tm = tm_nx; tn = tn_nx; At = At_nx; Wt = Wt_nx; a_ext = a_ext_nx; w_ext = w_ext_nx;
+    has_nx = vb + (int)gridDim.x < ntiles;
+    a_ext_nx = 0; w_ext_nx = 0;
+    if (has_nx) { tile_of(vb + (int)gridDim.x, tm_nx, tn_nx); tile_src(tm_nx, tn_nx, At_nx, Wt_nx, a_ext_nx, w_ext_nx); }
+    }
+    // The last iteration of the last tile still issued its 16 fragment reads into a0/b0 (nothing consumes them).  The compiler
+    // cannot see asm reads in flight, so keep those registers allocated to the end of the kernel: it must not hand them to the
+    // epilogue while the reads can still land.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a0[i]), "v"(b0[i]));
+#undef FAT_RD
+#undef FAT_MM
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -821,10 +893,18 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         static int fat = -1;
         if (fat < 0) { const char* e = getenv("SC_GEMM_FAT"); fat = e ? atoi(e) : 1; }
         if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31)) {
-            static bool fattr[8] = {};
-            if (!fattr[EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm_fat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); fattr[EPI] = true; }
-            hipLaunchKernelGGL((k_gemm_fat<EPI>), grid2, dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel);
+            // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
+            // fetched under the epilogue of the current one
+            const bool fp = persist && fat != 2 && nt_all > n_cu;
+            static bool fattr[8][2] = {};
+            if (!fattr[EPI][fp]) {
+                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                fattr[EPI][fp] = true;
+            }
+            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                                       (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
+            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                                    (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
         }

@@ -32,6 +32,8 @@ static inline size_t sc_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 
 typedef _Float16 sc_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sc_h4 __attribute__((ext_vector_type(4)));
+typedef unsigned sc_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned sc_u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 sc_h2 __attribute__((ext_vector_type(2)));
 typedef float sc_f4 __attribute__((ext_vector_type(4)));
 typedef float sc_f16v __attribute__((ext_vector_type(16)));

@@ -38,6 +38,20 @@ def test_gemm_vs_torch_fp32(M, N, K, epi):
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
+def test_gemm_operand_larger_than_2_gib():
+    """A of 2.2 GiB (the 512-frame ViT batches are this large): tiles address their rows through per-tile buffer resources, so
+    32-bit offsets never see the whole operand.  Checked on the first and last rows against torch on the same slices."""
+    M, N, K = 270000, 256, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = (torch.rand((M, K), generator=g, device="cuda") - 0.5).half()
+    w, b = _rand((N, K), 21, K ** -0.5), _rand((N,), 22)
+    out = ops.gemm(a, w, b, None, "quick_gelu")
+    for sl in (slice(0, 300), slice(M - 300, M)):
+        ref = a[sl].float() @ w.float().t() + b.float()
+        ref = ref * torch.sigmoid(1.702 * ref)
+        torch.testing.assert_close(out[sl].float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_gemm_strided_a_and_f32_out():
     a_full = _rand((200, 3072), 5)
     a = a_full[:, 1024:2048]                                                       # row-strided view, lda = 3072
