@@ -712,7 +712,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
             }
         }
     } else {
+#ifdef FAT_NOSTORE    // timing experiment only (profiles/r01_run167): every store is dropped by the range check
+        const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, 0);
+#else
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
+#endif
         const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
