@@ -266,7 +266,7 @@ def main():
         traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_gemm_all"]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    roof = dict(bound="mfma", kernel="k_gemm256 (+k_gemm128 for M<1024 or N%256)", launches=n, avg_ms=round(ms / max(n, 1), 5),
+    roof = dict(bound="mfma", kernel="k_gemm_fat (+k_gemm256/k_gemm128/k_gemm_skinny for K%128, small-M and fp32-out shapes)", launches=n, avg_ms=round(ms / max(n, 1), 5),
                 achieved=round(work / max(ms, 1e-9) / 1e9, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
                 frac=round(work / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4), traffic=traffic,
                 flops_per_launch=round(work / max(n, 1)))
