@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // One DMA instruction moves 64 rows x 64 B of one plane; the two planes of the same rows are issued back to back, so both
     // halves of every 128-byte line of the operand are consumed while the line is in flight / in the L1 (fetching the halves a
     // K-step apart, as with K = 32 stages, costs twice the L2 -> L1 line traffic).
-    constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB;
+    constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB, BIAS_OFF = 2 * BUF;        // + 8 KiB of bias slots behind the two buffers
     const int dr = tid >> 2, dc = (tid & 3) ^ swzF(tid >> 4);
     // buffer resources are rebased per tile (base = first row of the tile, extent = its valid rows), so operands of any size work
     // with 32-bit offsets and rows past M / N read as zeros; the four 64-row groups of a DMA round set get their own lane offsets
@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         }
 
     sc_f4 acc[8][8];
+    int tcount = 0;                                             // tiles done by this workgroup
 
     // The main loop is laid out by hand: MFMAs (accumulators tied in place in AGPRs), fragment reads and waits are volatile asm
     // in program order, because hipcc's allocator otherwise rotates the 256 accumulation registers through VGPRs every step.
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     auto iter = [&](auto Xc, int k) {
         constexpr int X = decltype(Xc)::value;
         const int fin = (k + 1 >= nk) ? 1 : 0;
+        const int relax = (PERSIST && k == 0 && tcount > 0) ? 1 : 0;       // stores of the previous tile's epilogue may still be in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int hi = 0; hi < 16; ++hi)
@@ -637,7 +639,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         for (int j = 0; j < 8; ++j) {
             const int t = hi * 8 + j, i = hi & 7;
             if (t == RB) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-            if (t == RC) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory"); __builtin_amdgcn_s_barrier(); }
+            if (t == RC) {
+                // iteration k + 1 (issued one iteration ago) has landed when at most the DMA rounds of this iteration are in flight; in
+                // the first iteration after an epilogue its C stores (younger than that DMA, same in-order counter) may stay in flight too
+                if (X == 0) asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\ts_cbranch_vccz .Lfat_w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lfat_x%=\n.Lfat_w%=:\n\ts_waitcnt vmcnt(%0)\n.Lfat_x%=:"
+                                        ::"n"(DMA_BEFORE_RC), "n"(DMA_BEFORE_RC + 1 + (EPI == SC_EPI_SWIGLU ? 16 : 32)), "v"(relax) : "vcc", "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             if (t < 64) FAT_MM(i, j, a0, b0);
             else if (X == 0 || t < 127) FAT_MM(i, j, a1, b1);
             else    // last MFMA of an iteration pair: after the tile's final one, drain the MFMA pipe INSIDE the same asm statement
@@ -654,6 +663,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         }
     };
     for (;;) {                                                  // tiles of this workgroup (one unless PERSIST)
+    // The tile's bias goes to LDS by DMA now (each wave its own 128 columns, 1 KiB slot per wave and tile parity; lanes >= 16 and a
+    // null bias are out of range -> zeros): a vector load in the epilogue would make hipcc wait (vmcnt is in order) for the DMA
+    // prefetch of the next tile and for the C stores issued before it.  The wait at RC of iteration 0 covers this DMA.
+    {
+        const int n0b = __builtin_amdgcn_readfirstlane(tn * BN2 + wc * 128);
+        lds_load16(bias ? bias + n0b : W, bias ? 256u : 0u, smem + BIAS_OFF + ((tcount & 1) * 4 + wave) * 1024, (unsigned)lane * 16u, 0u);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -676,8 +692,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // The range check of a buffer access covers the VGPR offset only (not the scalar offset), so the row part of every address
     // stays in the VGPR offset and only column steps go to the scalar one.  The row steps are made opaque per tile: otherwise
     // hipcc precomputes all 64 row offsets outside the tile loop and spills them.
-    int rstep_c = 32 * ldc, rstep_r = 32 * ldr;
-    asm volatile("" : "+v"(rstep_c), "+v"(rstep_r));
+    int rstep_c = 32 * ldc, rstep_r = 32 * ldr, rl_e = rl, g_e = g;     // (lane coordinates too: three hoisted offsets were spilled
+    asm volatile("" : "+v"(rstep_c), "+v"(rstep_r), "+v"(rl_e), "+v"(g_e));  //  and their reload waited for the whole DMA prefetch)
     auto pack2 = [](float x, float y) -> unsigned { const sc_h2 h = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(unsigned, h); };
     auto h4f = [](sc_u2 v, float (&f)[4]) {
         const unsigned x0 = v.x, x1 = v.y;                      // (bit_cast straight from v[1] miscompiles to element 0 with this hipcc)
@@ -685,14 +701,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         f[0] = (float)lo[0]; f[1] = (float)lo[1]; f[2] = (float)hi[0]; f[3] = (float)hi[1];
     };
     _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
-    const __amdgpu_buffer_rsrc_t rs_b = uniform_rsrc(bias ? bias + n0 : W, bias ? 256 : 0);
+    const char* bslot = smem + BIAS_OFF + ((tcount & 1) * 4 + wave) * 1024 + g_e * 8;         // + nj * 32: this lane's 4 bias values
     if (EPI == SC_EPI_SWIGLU) {
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + (n0 >> 1), rv * ldc * 2);
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {                        // two groups of four 16-column tiles -> 32 output columns each
             float bv[4][4];
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) h4f(__builtin_amdgcn_raw_buffer_load_b64(rs_b, g * 8, (q4 * 4 + nj) * 32, 0), bv[nj]);
+            for (int nj = 0; nj < 4; ++nj) h4f(*reinterpret_cast<const sc_u2*>(bslot + (q4 * 4 + nj) * 32), bv[nj]);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 unsigned d[4];
@@ -707,57 +723,73 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 const auto q0 = __builtin_amdgcn_permlane32_swap(p0[0], p1[0], false, false);
                 const auto q1 = __builtin_amdgcn_permlane32_swap(p0[1], p1[1], false, false);
                 unsigned w0 = q0[0], w1 = q1[0], w2 = q0[1], w3 = q1[1];
-                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl * ldc + g * 8) * 2 + mi * rstep_c, q4 * 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl_e * ldc + g_e * 8) * 2 + mi * rstep_c, q4 * 64, 0);
                 asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));      // see the note at the other store below
             }
         }
     } else {
-#ifdef FAT_NOSTORE    // timing experiment only (profiles/r01_run167): every store is dropped by the range check
-        const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, 0);
-#else
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
-#endif
         const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
+        // one step = a column pair (two 16-column tiles) x four row tiles: bias + activation + residual, 16-byte stores
+        auto step = [&](int st, const sc_u2 (&rr)[4][2]) {
+            const int pr = st >> 1, mh = st & 1;
+            __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: hipcc otherwise pulls all accumulator reads up front and spills
             float bv[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) h4f(__builtin_amdgcn_raw_buffer_load_b64(rs_b, g * 8, (2 * pr + h) * 32, 0), bv[h]);
+            for (int h = 0; h < 2; ++h) h4f(*reinterpret_cast<const sc_u2*>(bslot + (2 * pr + h) * 32), bv[h]);
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {                    // residual loads of four row tiles in flight together
-                sc_u2 rr[4][2];
+            for (int mq = 0; mq < 4; ++mq) {
+                const int mi = mh * 4 + mq;
+                unsigned lo[2], hi[2];
 #pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
+                for (int h = 0; h < 2; ++h) {
+                    const int nj = 2 * pr + h;
+                    float v[4], r4[4];
+                    h4f(rr[mq][h], r4);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        rr[mq][h] = R ? __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rl * ldr + g * 4) * 2 + (mh * 4 + mq) * rstep_r, (2 * pr + h) * 32, 0) : sc_u2{0u, 0u};
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq) {
-                    const int mi = mh * 4 + mq;
-                    unsigned lo[2], hi[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int nj = 2 * pr + h;
-                        float v[4], r4[4];
-                        h4f(rr[mq][h], r4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI) + r4[e];
-                        (h ? hi : lo)[0] = pack2(v[0], v[1]);
-                        (h ? hi : lo)[1] = pack2(v[2], v[3]);
-                    }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-                    // gfx950: a VALU write to the data registers of a 16-byte buffer store in the very next instruction corrupts the
-                    // stored value (seen as garbage in lanes 12..15 of each row of 16; profiles/r01_run161) and hipcc does not guard
-                    // it: the asm keeps the four registers allocated past the store and puts wait states before any reuse
-                    unsigned w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];
-                    __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl * ldc + (g & 1) * 16 + (g >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32, 0);
-                    asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI) + r4[e];
+                    (h ? hi : lo)[0] = pack2(v[0], v[1]);
+                    (h ? hi : lo)[1] = pack2(v[2], v[3]);
                 }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                // gfx950: a VALU write to the data registers of a 16-byte buffer store (scalar offset form) in the very next instruction
+                // corrupts the stored value (seen as garbage in lanes 12..15 of each row of 16; profiles/r01_run161) and hipcc does not
+                // guard it: the asm keeps the four registers allocated past the store and puts wait states before any reuse
+                unsigned w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl_e * ldc + (g_e & 1) * 16 + (g_e >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32, 0);
+                asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
             }
+        };
+        auto load_res = [&](int st, sc_u2 (&rr)[4][2]) {
+            const int pr = st >> 1, mh = st & 1;
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    rr[mq][h] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rl_e * ldr + g_e * 4) * 2 + (mh * 4 + mq) * rstep_r, (2 * pr + h) * 32, 0);
+        };
+        if (R) {
+            // the residual of step st + 1 is requested BEFORE the stores of step st are issued: vmcnt retires in order, so a load issued
+            // behind stores could only be consumed after those stores have completed (write latency exposed on every step)
+            sc_u2 ra[4][2], rb[4][2];
+            load_res(0, ra);
+#pragma unroll
+            for (int st = 0; st < 8; st += 2) {
+                load_res(st + 1, rb); step(st, ra);
+                if (st + 2 < 8) load_res(st + 2, ra);
+                step(st + 1, rb);
+            }
+        } else {
+            sc_u2 rz[4][2];
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq) { rz[mq][0] = sc_u2{0u, 0u}; rz[mq][1] = sc_u2{0u, 0u}; }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) step(st, rz);
         }
     }
     }
+    ++tcount;
     if (!has_nx) break;
     vb += (int)gridDim.x;
     tm = tm_nx; tn = tn_nx; At = At_nx; Wt = Wt_nx; a_ext = a_ext_nx; w_ext = w_ext_nx;
@@ -902,12 +934,12 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             const bool fp = persist && fat != 2 && nt_all > n_cu;
             static bool fattr[8][2] = {};
             if (!fattr[EPI][fp]) {
-                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
                 fattr[EPI][fp] = true;
             }
-            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                        (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
-            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 131072, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                     (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
