@@ -928,7 +928,9 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
         static int fat = -1;
         if (fat < 0) { const char* e = getenv("SC_GEMM_FAT"); fat = e ? atoi(e) : 1; }
-        if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31)) {
+        if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31) && lda % 8 == 0 &&
+            (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&          // 16-byte DMA granules
+            (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!R || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(R) & 7) == 0))) {
             // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
             // fetched under the epilogue of the current one
             const bool fp = persist && fat != 2 && nt_all > n_cu;

@@ -52,6 +52,15 @@ def test_gemm_operand_larger_than_2_gib():
         torch.testing.assert_close(out[sl].float(), ref, rtol=2e-3, atol=2e-3)
 
 
+def test_gemm_unaligned_bias_takes_the_fallback_kernel():
+    """a bias view that is not 16-byte aligned cannot be fetched by the DMA of the 4-wave kernel: the dispatcher has to fall back"""
+    M, N, K = 1300, 512, 1024
+    a, w = _rand((M, K), 31), _rand((N, K), 32, K ** -0.5)
+    b = _rand((N + 4,), 33)[4:]                                                    # 8-byte offset: legal for the ABI, not for the DMA
+    out = ops.gemm(a, w, b, None, "none")
+    torch.testing.assert_close(out.float(), a.float() @ w.float().t() + b.float(), rtol=2e-3, atol=2e-3)
+
+
 def test_gemm_strided_a_and_f32_out():
     a_full = _rand((200, 3072), 5)
     a = a_full[:, 1024:2048]                                                       # row-strided view, lda = 3072
