@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         constexpr int X = decltype(Xc)::value;
         const int fin = (k + 1 >= nk) ? 1 : 0;
         const int relax = (PERSIST && k == 0 && tcount > 0) ? 1 : 0;       // stores of the previous tile's epilogue may still be in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // s_nop: the accumulators are zeroed by VALU writes in the loop preheader and the hazard recognizer does not know that the asm
+        // below reads them as MFMA SrcC; everything after this statement is in the loop body, so three wait states are guaranteed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
 #pragma unroll
         for (int hi = 0; hi < 16; ++hi)
 #pragma unroll
