@@ -6,6 +6,9 @@
 // linears (llava_qwen.py:155).  Weights keep the torch.nn.Linear layout W[N,K] ("B^T input"), so both
 // MFMA operands are read along K with 16-byte ds_read_b128.
 //
+// Three generations live here: k_gemm_fat (v3, below: the default for the large GEMMs), k_gemm256 (v2: 8 waves, K = 32 ring; now the
+// fallback for K % 128 != 0, fp32 output and the row-mapped A operand), k_gemm128 (v1: small M / N % 256 != 0) and k_gemm_skinny (M <= 32).
+//
 // Structure (v1): 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 fragments of
 // v_mfma_f32_16x16x32_f16 (fp32 accumulate).  Tiles are staged HBM->LDS with 16-byte
 // global_load_lds (no VGPR round trip); the LDS image is lane-linear, so the bank-conflict-free
@@ -518,11 +521,12 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// v3 ("fat waves"): the same 256x256 tile and 4-slot LDS ring, but FOUR waves (2 x 2), each owning 128 x 128 of the tile:
-// 64 accumulator tiles per wave (256 accumulation registers: the compiler keeps them in AGPRs, one wave per SIMD with the whole
-// 512-register file), 16 fragment reads per 64 MFMAs.  LDS fragment traffic per MFMA drops from 0.375 KB (128x64 wave tiles)
-// to 0.25 KB, which is what the LDS-DMA writes of the ring compete with; K-steps are 64 MFMAs long, so the 16 fragment reads
-// and 8 DMA issues of the next steps hide under them with room to spare.
+// v3, k_gemm_fat - the DEFAULT kernel for fp16 output with K % 128 == 0 (every large GEMM of the ViT and the LLM):
+// the same 256x256 tile, but FOUR waves (2 x 2), one per SIMD with the whole 512-register file, each owning 128 x 128 of the tile:
+// 64 accumulator tiles (all 256 AGPRs), K = 64 per iteration out of two 64-KiB LDS buffers, 32 ds_read_b128 per 128 MFMAs (0.25 KiB
+// of LDS fragment traffic per MFMA against 0.375 for the 128x64 wave tiles of k_gemm256).  The K loop is scheduled by hand (asm MFMAs
+// with the accumulator tied in place, asm fragment reads, explicit waits, DMA rounds spread one per 7 MFMAs); what that bought, what
+// it needed (whole 128-byte lines per DMA pair, no bursts) and the hazards it runs into are written up in DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------------------------
 template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
