@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the streaming hot path on MI355X (driver contract in the task brief).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config C1|C2|C3|C4]   (N > 1: under torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one synthetic 1024-frame 336x336 stream per GPU:
+A "step" is one pass of the hot path over one synthetic 336x336 frame stream:
   encode   uint8 frames -> fused preprocess/patchify -> ViT-L/14-336 (23 layers) -> mlp2x_gelu projector   [MFMA]
   select   forgetting-curve short memory + chunking + memory-tree update incl. ONE whole-frame k-means
            (T = 400 frames, K = 5, D = 576*3584)                                                            [HBM]
   retrieve caption / dialogue embeddings -> cosine / flat-L2 top-k -> tree search                           [latency]
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0)."""
+  answer   [short | retrieved] frame tokens + prompt -> Qwen2-7B prefill + first token                      [MFMA]
+Workloads (BASELINE.json configs):  C3 (default, the configuration the metric is quoted on): 1024 frames per GPU, full path;
+C2 = C3 without the LLM; C1 = 64 frames, encode + k-means(k=8); C4 = ONE 4096-frame stream sharded over the N ranks
+(strong scaling), all-gather of the selected features, 7B prefill on rank 0.  With N > 1 the stream is ONE global stream dealt to
+the ranks by whole chunks and the memory update has single-stream semantics (streamchat_amd/sharded.py): the retrieved frames do
+not depend on N.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0)."""
 import argparse
 import json
 import os
@@ -21,8 +26,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from streamchat_amd import dist as DD, llm as LM, ops, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
+from streamchat_amd import dist as DD, llm as LM, ops, sharded as SH, streaming as S, synthetic, text as T, utiles as U, vision as V   # noqa: E402
 from streamchat_amd.memory_bank.memory_retrieval import local_doc_qa as Q   # noqa: E402
+from streamchat_amd.mm_utils import tokenizer_image_token   # noqa: E402
 
 FRAMES = 1024
 MICRO_BATCH = int(os.environ.get("SC_MICRO_BATCH", "512"))     # frames per ViT pass: 512 x 577 rows = 1154 whole 256-row GEMM tiles, 6.6 GB of activations
@@ -30,6 +36,7 @@ MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_PROFILE = "profiles/r01_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 
 
 def parse():
@@ -37,26 +44,35 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4"], default=None)
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (C2/C3) or in total (C1/C4); default: the config's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llm", action="store_true", help="C2 workload: stop after retrieval (no 7B prefill)")
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
     return ap.parse_args()
 
 
 class Pipeline:
-    def __init__(self, device, n_frames, seed, with_llm=True):
+    """`n_total` frames of ONE global stream; this rank holds (and encodes) the frames `parts[rank]` of it."""
+
+    def __init__(self, device, n_total, seed=1234, with_llm=True, ctx=None, micro_batch=MICRO_BATCH, kmeans_k=None):
+        self.ctx = ctx or DD.DistContext(0, 1, device)
         cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
         self.cfg = cfg
         self.sd_vit = V.random_clip_state_dict(cfg, seed=0, device=device)
         self.sd_proj = V.random_projector_state_dict(1024, 3584, seed=1, device=device)
-        self.enc = V.FrameEncoder(V.CLIPVisionTower(self.sd_vit, cfg, device=device), V.MMProjector(self.sd_proj, device=device), micro_batch=MICRO_BATCH)
-        self.frames = torch.from_numpy(synthetic.frame_stream(n_frames, seed=seed)).to(device)        # resident in HBM
-        self.feats = torch.empty((n_frames, cfg.num_patches, 3584), dtype=torch.float16, device=device)
+        self.enc = V.FrameEncoder(V.CLIPVisionTower(self.sd_vit, cfg, device=device), V.MMProjector(self.sd_proj, device=device), micro_batch=micro_batch)
+        self.n_total = n_total
+        self.parts = DD.partition_chunks(n_total, MEM["chunk_size"], self.ctx.world)
+        a, b = self.parts[self.ctx.rank]
+        self.range, self.n = (a, b), b - a
+        self.frames = torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=a)).to(device)        # resident in HBM
+        self.feats = torch.empty((b - a, cfg.num_patches, 3584), dtype=torch.float16, device=device)
         self.device = device
-        self.n = n_frames
+        self.kmeans_k = kmeans_k
+        self.enc_events = []
         # retrieval models: BERT-large (mxbai-colbert as the reference loads it: plain encoder, CLS) for the caption tree,
         # all-MiniLM-L6 (mean-pool + L2-normalise) for the dialogue memory; random-init, hash tokenizer (offline)
         bl, ml = T.BertConfigLite(**T.BERT_LARGE), T.BertConfigLite(**T.MINILM_L6)
@@ -67,95 +83,97 @@ class Pipeline:
                                 f"[|AI|]: {synthetic.caption(200 + i, words=10)}", {"source": f"2024-05-{1 + i // 8:02d}"}) for i in range(32)]
         self.question = "where did I leave the red cup and what was on the kitchen table"
         self.model = None
-        if with_llm:        # LongVA-7B language side: Qwen2-7B shape, random-init fp16 (15 GB), KV cache for 64k tokens
+        if with_llm:        # LongVA-7B language side: Qwen2-7B shape, random-init fp16 (15 GB), KV cache for 52k tokens
             qc = LM.Qwen2ConfigLite(**LM.QWEN2_7B)
             sd = LM.random_qwen2_state_dict(qc, seed=4, device=device)
             self.model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, qc, device=device, max_seq=53248, consume=True), self.enc)
             del sd
             torch.cuda.empty_cache()
         self.llm_tok = synthetic.SyntheticTokenizer()
+        self.last = {}
 
-    def step(self):
-        # ---- encode ----
-        self.enc.encode_frames_u8(self.frames, out=self.feats)
-        bank = [self.feats[i:i + 1] for i in range(self.n)]
-        # ---- select (memory update; captions come from the synthetic captioner, untimed-equivalent host work) ----
-        cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
-        torch.manual_seed(0)                                  # init_idx = CPU randperm(T)[:K]  
-        tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
-        # ---- retrieve: dialogue memory (MiniLM, flat L2, k=1, rebuilt per round like memory_utils.py:76-83) ----
+    # ---- stages ----
+    def _tag(self, t):
+        if ops.KernelTimer.active is not None:
+            ops.KernelTimer.active.tag = t
+
+    def encode(self):
+        self._tag("encode")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if self.n:
+            self.enc.encode_frames_u8(self.frames, out=self.feats)
+        e1.record()
+        self.enc_events.append((e0, e1))
+
+    def dialogue_search(self):
+        # dialogue memory (MiniLM, flat L2, k=1, rebuilt per round like memory_utils.py:76-83)
         lm = Q.LocalMemoryRetrieval()
         lm.init_cfg("minilm-l6", top_k=1, language="en", embedder=self.sent)
         store = Q.FlatL2VectorStore(self.docs, lm._embed_docs(self.docs), self.sent.embed_query)
-        related, dates = lm.search_memory(self.question, store)
-        # ---- retrieve: caption-tree search (BERT-large CLS + cosine, strict > 0 rule, utiles.py:685-788) ----
+        return lm.search_memory(self.question, store)
+
+    def prefill(self, image_embeddings, caption):
+        self._tag("prefill")
+        qs = S.build_answer_prompt(self.question, caption, None)
+        conv = S.conv_templates["qwen_1_5"].copy()
+        conv.append_message(conv.roles[0], qs)
+        conv.append_message(conv.roles[1], None)
+        ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
+        out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
+                                                       max_new_tokens=1)
+        self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
+
+    def step(self):
+        """single GPU, through the reference-seam functions (streaming.updating_memory_buffer, utiles.fast_search_tree_...)"""
+        self.encode()
+        self._tag("select")
+        bank = [self.feats[i:i + 1] for i in range(self.n)]
+        cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
+        torch.manual_seed(0)                                  # init_idx = CPU randperm(T)[:K]  (SURVEY §8(d))
+        if self.kmeans_k:                                     # C1: ONE weighted_kmeans_feature(X[64,576,3584], 8) over all frames
+            red, labels = U.weighted_kmeans_feature(self.feats, self.kmeans_k)
+            self.last = dict(labels=labels, reduced=red)
+            return self.last
+        tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
+        self._tag("retrieve")
+        related, dates = self.dialogue_search()
+        # caption-tree search (BERT-large CLS + cosine, strict > 0 rule, utiles.py:685-788)
         short_emb = U.cat_frames(short).view(-1, short[0].shape[-1])
         path_feats, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, short_emb, self.colbert, self.tok,
                                                                               cache=U.CaptionEmbeddingCache())
         self.last = dict(tree=tree, short=short, related=related, path_text=path_text, path_feats=path_feats)
-        # ---- answer-time 7B prefill over [short | long] frame tokens + prompt (first answer token) ----
         if self.model is not None:
             long_emb = torch.cat([t.reshape(-1, t.shape[-1]) for t in path_feats], dim=0)
-            image_embeddings = torch.cat([short_emb, long_emb], dim=0)
-            qs = S.build_answer_prompt(self.question, path_text[-1], None)
-            conv = S.conv_templates["qwen_1_5"].copy()
-            conv.append_message(conv.roles[0], qs)
-            conv.append_message(conv.roles[1], None)
-            from streamchat_amd.mm_utils import tokenizer_image_token
-            ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
-            out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
-                                                           max_new_tokens=1)
-            self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
+            self.last["image_embeddings"] = image_embeddings = torch.cat([short_emb, long_emb], dim=0)
+            self.prefill(image_embeddings, path_text[-1])
         return self.last
 
-    def step_sharded(self, ctx):
-        """N > 1: the stream of world*frames frames is dealt to the ranks by whole chunks.  Encode, chunk captions and the chunk-group
-        k-means are rank-local; rank 0 searches the all-gathered node METADATA; only the selected frames (short memory + retrieved
-        chunks) cross xGMI in one fixed-capacity all_gather; rank 0 prefills the 7B model."""
-        parts = DD.partition_chunks(self.n * ctx.world, MEM["chunk_size"], ctx.world)
-        a, b = parts[ctx.rank]
-        self.enc.encode_frames_u8(self.frames[: b - a], out=self.feats[: b - a])
-        bank = [self.feats[i:i + 1] for i in range(b - a)]
+    def step_sharded(self):
+        """N >= 1 ranks: encode and chunk captions are rank-local; the tree policy, the ONE merge-group k-means, the retrieval and
+        the prefill are those of the single stream (sharded.ShardedMemory); only the selected rows cross xGMI (one all-gather)."""
+        ctx = self.ctx
+        self.encode()
+        self._tag("select")
         cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
-        cap.n = a // MEM["chunk_size"]                                     # global chunk numbering of the synthetic captions
         torch.manual_seed(0)
-        tree, short = S.updating_memory_buffer(bank, None, cap, tok, True, rng=np.random.RandomState(0), **MEM)
-        # ---- metadata to rank 0: per top-level node (depth, text, children (text, frame range)), + short-memory frame ids ----
-        base = self.feats.data_ptr()
-        fsz = self.feats[0].numel() * self.feats.element_size()
-        gidx = lambda t: a + (t.data_ptr() - base) // fsz                     # global index of a bank view's first frame
-        def desc(n):
-            rng = (int(gidx(n.centroids)), int(gidx(n.centroids)) + n.centroids.shape[0]) if n.depth == 0 else None
-            return dict(depth=n.depth, text=n.text, frames=rng, children=[desc(c) for c in n.children])
-        meta = DD.gather_objects(ctx, dict(nodes=[desc(n) for n in tree], short=[int(gidx(t)) for t in short]))
-        wanted = None
+        mem = SH.ShardedMemory(ctx, **MEM)
+        tree, short = mem.update(self.feats, self.n_total, cap, tok, rng=np.random.RandomState(0))
+        self._tag("retrieve")
+        wanted, path_text, related = None, None, None
         if ctx.is_root:
-            def proxy(d):
-                n = U.MultimodalTreeNode(d["frames"], d["text"], depth=d["depth"])
-                n.children = [proxy(c) for c in d["children"]]
-                return n
-            nodes = [proxy(d) for m in meta for d in m["nodes"]]
-            lm = Q.LocalMemoryRetrieval()
-            lm.init_cfg("minilm-l6", top_k=1, language="en", embedder=self.sent)
-            lm.search_memory(self.question, Q.FlatL2VectorStore(self.docs, lm._embed_docs(self.docs), self.sent.embed_query))
-            path, path_text = U.fast_search_tree_multi_modal_with_embedding(nodes, self.question, self.feats[0], self.colbert, self.tok,
+            related, dates = self.dialogue_search()
+            path, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, self.feats, self.colbert, self.tok,
                                                                             cache=U.CaptionEmbeddingCache())
-            wanted = list(meta[-1]["short"]) + [f for rng in path for f in range(rng[0], rng[1])]
-            self.last = dict(path_text=path_text)
-        wanted = DD.broadcast_object(ctx, wanted)
-        sel = DD.gather_selected_frames(ctx, self.feats[: b - a], (a, b), wanted, capacity=2 * MEM["chunk_size"] + MEM["remember_window"])
-        if ctx.is_root and self.model is not None:
-            image_embeddings = sel.reshape(-1, sel.shape[-1])
-            qs = S.build_answer_prompt(self.question, self.last["path_text"][-1], None)
-            conv = S.conv_templates["qwen_1_5"].copy()
-            conv.append_message(conv.roles[0], qs)
-            conv.append_message(conv.roles[1], None)
-            from streamchat_amd.mm_utils import tokenizer_image_token
-            ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
-            out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
-                                                           max_new_tokens=1)
-            self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
-        return self.last if ctx.is_root else None
+            wanted = list(short) + list(path)
+        wanted = mem.broadcast_refs(wanted)
+        sel = mem.fetch(wanted, dst=0, mode="allgather")
+        self.last = dict(tree=tree, wanted=[mem.frames_of(r) for r in wanted], path_text=path_text, related=related, mem=mem)
+        if ctx.is_root:
+            self.last["image_embeddings"] = image_embeddings = sel.reshape(-1, sel.shape[-1])
+            if self.model is not None:
+                self.prefill(image_embeddings, path_text[-1])
+        return self.last
 
     def decode_rate(self, n_tokens):
         """greedy decode tokens/s on the context left in the KV cache by the last step (reported separately from the metric)"""
@@ -170,44 +188,71 @@ class Pipeline:
         return n_tokens / (time.perf_counter() - t0)
 
 
-def cpu_baseline(pipe, n_cpu_frames):
+def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     """The CPU restatement of the reference path (oracle/torch_ref.py: plain fp32 PyTorch, the arithmetic the reference's CPU path
-    runs) timed on this box's host cores on a bounded sample and scaled to the full workload (the scaling rule is in `sample`)."""
+    runs) timed on this box's host cores on a BOUNDED sample of the same workload and scaled to it (the scaling
+    rules are spelled out in `sample`): ViT-L + projector on `n_cpu_frames` frames at the best of a thread sweep, the reference's
+    [T,K,D]-broadcast k-means formula for two iterations at C1's size, a real 2-layer Qwen2-7B-shape fp32 prefill of 2048 tokens."""
     from oracle import torch_ref as R
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)                      # PyTorch CPU GEMMs stop scaling (and oversubscribe) far below 256 threads
-    torch.set_num_threads(threads)
     sd = {k: v.float().cpu() for k, v in pipe.sd_vit.items()}
     sp = {k: v.float().cpu() for k, v in pipe.sd_proj.items()}
     u8 = pipe.frames[:n_cpu_frames].cpu().numpy()
-    x = (u8.astype(np.float64) * (1 / 255)).astype(np.float32)
-    x = torch.from_numpy(np.ascontiguousarray(((x - np.asarray(ops.CLIP_MEAN, np.float32)) / np.asarray(ops.CLIP_STD, np.float32)).transpose(0, 3, 1, 2)))
+    x = torch.from_numpy(R.preprocess_u8(u8))
+    best = None
     with torch.no_grad():
-        R.encode_images(sd, sp, x[:1], heads=16, patch=14, num_layers=24)          # warm-up (thread pool, allocator)
+        for th in [t for t in (16, 32, 64, 128, 256) if t <= cores] or [cores]:           # thread sweep on 2 frames
+            torch.set_num_threads(th)
+            R.encode_images(sd, sp, x[:1], heads=16, patch=14, num_layers=24)              # warm-up (thread pool, allocator)
+            t0 = time.time()
+            R.encode_images(sd, sp, x[:2], heads=16, patch=14, num_layers=24)
+            dt = (time.time() - t0) / 2
+            if best is None or dt < best[1]:
+                best = (th, dt)
+        threads = best[0]
+        torch.set_num_threads(threads)
         t0 = time.time()
         R.encode_images(sd, sp, x, heads=16, patch=14, num_layers=24)
-    t_frame = (time.time() - t0) / n_cpu_frames
-    # select: the reference's [T,K,D] broadcast k-means on 40 of the 400 merge-group frames, full width (cost is linear in T)
-    Tsub = 40
-    Xs = pipe.feats[:400:10].reshape(Tsub, -1).float().cpu()
-    t0 = time.time()
-    _, _, _, it = R.weighted_kmeans_reference_formula(Xs, 5, list(range(0, Tsub, Tsub // 5))[:5], [0] * 50, max_iter=2)
-    t_km_iter = (time.time() - t0) / (it + 1) * (400 / Tsub)
-    km_iters = 3
-    # 7B prefill: flop model 2*N*6.53e9 + 2*N^2*3584*28 (SURVEY 8(d)) at the CPU's measured ViT GEMM rate
-    t_prefill = 0.0
-    note = ""
+        t_frame = (time.time() - t0) / n_cpu_frames
+    # select: the reference's [T,K,D] broadcast k-means at C1's size (T=64, K=8, D=2064384), two iterations; the merge k-means of the
+    # 1024-frame stream (T=400, K=5) costs (400*5)/(64*8) of it per iteration (the formula is linear in T*K*D)
+    Xs = pipe.feats[:64].reshape(64, -1).float().cpu() if pipe.n >= 64 else None
+    t_km_iter = 0.0
+    if Xs is not None:
+        t0 = time.time()
+        _, _, _, it = R.weighted_kmeans_reference_formula(Xs, 8, list(range(0, 64, 8)), [0] * 80, max_iter=2)
+        t_km_iter = (time.time() - t0) / (it + 1)
+    del Xs
+    c1 = 64 / (64 * t_frame + 10 * t_km_iter)                  # C1 in full: 64 frames + k-means(k=8), <= 10 iterations
+    km = km_iters_gpu * t_km_iter * (400 * 5) / (64 * 8)
+    # answer: a REAL fp32 prefill of 2048 tokens through 2 Qwen2-7B-shape layers (+ final norm / lm_head), extrapolated with the
+    # flop model 2*N*6.53e9 + 2*N^2*3584*28 (SURVEY 8(d)) at the rate measured on that run
+    t_prefill, note = 0.0, ""
     if pipe.model is not None and pipe.last.get("context"):
+        qc = LM.Qwen2ConfigLite(**dict(LM.QWEN2_7B, layers=2))
+        sdq = {k: v.float().cpu() for k, v in LM.random_qwen2_state_dict(qc, seed=4, device=pipe.device).items() if "embed_tokens" not in k and "lm_head" not in k}
+        sdq["lm_head.weight"] = torch.zeros(8, qc.hidden)       # 8-row head: the timed work is the decoder layers
+        n0 = 2048
+        emb = torch.randn(n0, qc.hidden) * 0.02
+        with torch.no_grad():
+            t0 = time.time()
+            R.qwen2_logits(sdq, emb, heads=qc.heads, kv_heads=qc.kv_heads, layers=2, head_dim=qc.head_dim)
+            dt = time.time() - t0
+        per_layer = (6.53e9 - 152064 * 3584) / 28
+        flops0 = 2 * (2 * n0 * per_layer + 2 * n0 * n0 * 3584)          # the reference's HF attention computes the full N x N scores
+        rate = flops0 / dt
         n = pipe.last["context"]
         flops = 2 * n * 6.53e9 + 2 * n * n * 3584 * 28 * 0.5 * 2
-        cpu_rate = 385.1e9 / t_frame
-        t_prefill = flops / cpu_rate
-        note = f"; 7B prefill of {n} tokens extrapolated with the flop model at the measured CPU rate ({cpu_rate / 1e12:.2f} TFLOP/s): {t_prefill:.0f} s"
-    total = pipe.n * t_frame + km_iters * t_km_iter + t_prefill
-    return dict(value=round(pipe.n / total, 5), unit="frames/s", cores=threads, kind="port",
-                sample=f"oracle/torch_ref ViT-L+projector fp32 on {n_cpu_frames} frames ({t_frame:.2f} s/frame, {threads} threads of {cores} cores) x{pipe.n}; "
-                       f"reference-formula k-means T={Tsub} of 400, K=5, D=2064384 scaled x10 ({t_km_iter:.2f} s/iter x {km_iters} iters)" + note
-                       + "; retrieval negligible")
+        t_prefill = flops / rate
+        note = (f"; 7B prefill: 2 Qwen2-7B-shape layers x {n0} tokens fp32 measured ({dt:.1f} s = {rate / 1e12:.2f} TFLOP/s), "
+                f"{n} tokens x 28 layers extrapolated with the flop model: {t_prefill:.0f} s")
+    n_frames = FRAMES
+    total = n_frames * t_frame + km + t_prefill
+    return dict(value=round(n_frames / total, 5), unit="frames/s", cores=threads, kind="port", c1_frames_per_s=round(c1, 4),
+                sample=f"oracle/torch_ref ViT-L+projector fp32 on {n_cpu_frames} frames ({t_frame:.2f} s/frame at {threads} threads, best of a sweep, {cores} "
+                       f"cores) x{n_frames}; reference-formula k-means at C1 size T=64,K=8,D=2064384: {t_km_iter:.2f} s/iter, scaled x{(400 * 5) / (64 * 8):.2f} "
+                       f"to the T=400,K=5 merge x {km_iters_gpu} iterations" + note + "; retrieval negligible; C1 (64 frames + k-means k=8, 10 iterations) "
+                       f"= {c1:.3f} frames/s")
 
 
 def main():
@@ -225,15 +270,19 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     ctx = DD.DistContext(rank, world, dev, "nccl")
-    # weak scaling: world * frames frames in total; the 7B model lives on rank 0 only (single-GPU LLM stage)
-    pipe = Pipeline(dev, a.frames + MEM["chunk_size"], seed=1234 + rank, with_llm=(not a.no_llm) and rank == 0) if world > 1 else \
-        Pipeline(dev, a.frames, seed=1234 + rank, with_llm=not a.no_llm)
-    if world > 1:
-        pipe.n = a.frames
-    if a.force_sharded and world == 1:
-        pipe = Pipeline(dev, a.frames + MEM["chunk_size"], seed=1234, with_llm=not a.no_llm)
-        pipe.n = a.frames
-    run_step = (lambda: pipe.step_sharded(ctx)) if (world > 1 or a.force_sharded) else pipe.step
+    config = a.config or ("C2" if a.no_llm else "C3")
+    full = config in ("C3", "C4")
+    if config == "C1":
+        n_total, scaling = a.frames or 64, "strong"
+    elif config == "C4":
+        n_total, scaling = a.frames or 4096, "strong"          # ONE 4096-frame stream over the N ranks
+    else:
+        n_total, scaling = (a.frames or FRAMES) * world, "weak"   # 1024 frames per GPU
+    sharded = world > 1 or a.force_sharded
+    if config == "C1" and sharded:
+        sys.exit("C1 (64 frames, one k-means over all of them) is a single-GPU configuration")
+    pipe = Pipeline(dev, n_total, with_llm=full and rank == 0, ctx=ctx, kmeans_k=8 if config == "C1" else None)
+    run_step = pipe.step_sharded if sharded else pipe.step
 
     def barrier():
         if world > 1:
@@ -244,6 +293,7 @@ def main():
     for _ in range(a.warmup):
         run_step()
     barrier()
+    pipe.enc_events.clear()
     t0 = time.perf_counter()
     with ops.KernelTimer() as kt:
         for _ in range(a.steps):
@@ -251,45 +301,82 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof = kt.summary()
+        km_infos = [i.cpu().tolist() for i in kt.aux.get("kmeans_info", [])]
+    t_enc = sum(e0.elapsed_time(e1) for e0, e1 in pipe.enc_events) / 1e3
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, t_enc], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, t_enc = float(tmax[0].item()), float(tmax[1].item())
     if rank != 0:
         return
     ms_step = dt / a.steps * 1e3
-    value = a.frames * world * a.steps / dt
-    n, ms, work = prof.get("k_gemm", (0, 0.0, 0.0))
+    value = n_total * a.steps / dt
+
+    def fam(suffix, tags=None):
+        """(launches, ms, work) summed over the records '<tag>/<suffix>' (all tags, or the given ones)"""
+        n = ms = w = 0
+        for k, v in prof.items():
+            t, _, s = k.rpartition("/")
+            if s == suffix and (tags is None or t in tags):
+                n, ms, w = n + v[0], ms + v[1], w + v[2]
+        return n, ms, w
+
+    def mfma_roof(name, rec):
+        n, ms, w = rec
+        return dict(bound="mfma", kernel=name, launches=n, avg_ms=round(ms / max(n, 1), 5), achieved=round(w / max(ms, 1e-9) / 1e9, 1),
+                    peak=MFMA_PEAK_TF, unit="TFLOP/s", frac=round(w / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4))
+
+    n, ms, work = fam("k_gemm")
     traffic = None
-    try:        # HBM bytes per launch from the committed PMC passes of this same command (profiles/, see its `correction` note)
-        traffic = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_gemm_all"]["hbm_bytes_per_launch"])
+    try:        # HBM bytes per launch from the committed PMC passes of this same command (separate --pmc runs; see the file's `correction` note)
+        traffic = round(json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))["kernels"]["k_gemm_all"]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    roof = dict(bound="mfma", kernel="k_gemm_fat (+k_gemm256/k_gemm128/k_gemm_skinny for K%128, small-M and fp32-out shapes)", launches=n, avg_ms=round(ms / max(n, 1), 5),
-                achieved=round(work / max(ms, 1e-9) / 1e9, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
-                frac=round(work / max(ms, 1e-9) / 1e9 / MFMA_PEAK_TF, 4), traffic=traffic,
-                flops_per_launch=round(work / max(n, 1)))
-    stages = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in prof.items()}
-    if "kmeans_fit" in prof:
-        kn, kms, kw = prof["kmeans_fit"]
-        stages["kmeans_fit"]["note"] = "whole Lloyd fit (assign+update per iteration)"
-    full = not a.no_llm
+    roof = mfma_roof("k_gemm_fat (+k_gemm256/k_gemm128/k_gemm_skinny for K%128, small-M and fp32-out shapes)", (n, ms, work))
+    roof.update(traffic=traffic, traffic_source=TRAFFIC_PROFILE if traffic else None, flops_per_launch=round(work / max(n, 1)))
+    # per-stage rooflines: the ViT and LLM halves of the two MFMA kernel families, the HBM-bound k-means (1x = SURVEY 8(d)'s algorithmic
+    # bytes: one read of X per Lloyd iteration; 2x = what the two-pass kernel moves), decode below
+    stages = dict(vit_gemm=mfma_roof("k_gemm* (ViT-L + projector)", fam("k_gemm", ("encode",))),
+                  vit_attention=mfma_roof("k_attn<64> S=577", fam("k_attn", ("encode",))))
+    if full:
+        stages.update(llm_gemm=mfma_roof("k_gemm* (Qwen2-7B prefill)", fam("k_gemm", ("prefill",))),
+                      llm_attention=mfma_roof("k_attn<128> causal GQA", fam("k_attn", ("prefill",))))
+    kn, kms, kw = fam("kmeans_fit")
+    if kn:
+        iters = sum(i[0] + 1 for i in km_infos) or kn           # assign(+update) passes actually run (device-side exit iteration + 1)
+        gbs = kw / kn * iters / max(kms, 1e-9) / 1e6
+        stages["kmeans"] = dict(bound="hbm", kernel="km_assign + km_update", launches=kn, lloyd_passes=iters, avg_ms=round(kms / kn, 4),
+                                achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                                frac_counting_both_reads_of_X=round(2 * gbs / HBM_PEAK_GBS, 4))
+    per = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in sorted(prof.items())}
+    enc_fps = n_total * a.steps / max(t_enc, 1e-9)
+    names = dict(C1="C1: 64-frame stream, ViT-L encode + ONE weighted_kmeans_feature(k=8) over all frames (no LLM)",
+                 C2="C2: 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, memory update (chunk 40, K 5, interval 10: one "
+                    "k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval",
+                 C3="C3: 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, memory update (chunk 40, K 5, interval 10: one "
+                    "k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval, LongVA-7B (Qwen2-7B shape) prefill of the retrieved context + first token",
+                 C4="C4: ONE 4096-frame stream sharded over the ranks by whole chunks, encode + chunk captions rank-local, single-stream tree policy "
+                    "(one k-means T=400), all-gather of the selected features, LongVA-7B prefill on rank 0")
     out = dict(metric="frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
-               "frames/sec end-to-end (encode+select+retrieve), 1024-frame stream", value=round(value, 2), unit="frames/s",
-               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
+               "frames/sec end-to-end (encode+select" + ("" if config == "C1" else "+retrieve") + f"), {n_total // (world if scaling == 'weak' else 1)}-frame stream",
+               value=round(value, 2), unit="frames/s",
+               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling=scaling,
                vs_baseline=None, dtype="f16", data="synthetic",
-               config=dict(workload=("C3" if full else "C2") + ": 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, "
-                                    "memory update (chunk 40, K 5, interval 10: one k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval"
-                                    + (", LongVA-7B (Qwen2-7B shape) prefill of the retrieved context + first token" if full else ""),
-                           context_tokens=pipe.last.get("context"),
-                           frames_per_gpu=a.frames, micro_batch=MICRO_BATCH, parallelism=f"dp{world}", weights="random-init"),
-               roofline=roof, stages=stages)
+               config=dict(workload=names[config], context_tokens=pipe.last.get("context"), frames_total=n_total, frames_rank0=pipe.n,
+                           micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""), weights="random-init"),
+               encode_frames_per_s=round(enc_fps, 1), encode_ms_per_step=round(t_enc / a.steps * 1e3, 2),
+               roofline=roof, roofline_stages=stages, stages=per)
     if full and a.decode_tokens > 0 and world == 1:
-        out["decode_tokens_per_s"] = round(pipe.decode_rate(a.decode_tokens), 2)         # greedy, batch 1, after the timed region (512 tokens)
+        rate = pipe.decode_rate(a.decode_tokens)         # greedy, batch 1, after the timed region (SURVEY C3: 512 tokens)
+        ctxlen = pipe.last["context"] + a.decode_tokens / 2
+        gb_tok = 14.1 + 2 * 28 * 4 * 128 * ctxlen * 2 / 1e9       # SURVEY 8(d): fp16 weights incl. lm_head + KV bytes per token
+        out["decode_tokens_per_s"] = round(rate, 2)
         out["decode_tokens"] = a.decode_tokens
-    if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames)
+        out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv + split-KV k_attn (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
+                                                unit="GB/s", frac=round(rate * gb_tok / HBM_PEAK_GBS, 4), gb_per_token=round(gb_tok, 2))
+    if not a.no_cpu_baseline and world == 1 and config in ("C2", "C3"):
+        out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames, max((i[0] + 1 for i in km_infos[-1:]), default=3))
     print(json.dumps(out))
 
 

@@ -38,6 +38,8 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.aux = {}               # side records (e.g. the device-side k-means info words of every fit)
+        self.tag = ""               # optional stage label set by the caller ("encode", "prefill", ...): records become "<tag>/<kernel>"
 
     def __enter__(self):
         KernelTimer.active = self
@@ -59,7 +61,7 @@ class _timed:
     def __init__(self, name, work):
         self.kt = KernelTimer.active
         if self.kt is not None:
-            self.name, self.work = name, work
+            self.name, self.work = (f"{self.kt.tag}/{name}" if self.kt.tag else name), work
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
@@ -118,6 +120,8 @@ def kmeans_fit(X: torch.Tensor, K: int, init_idx, reseed_idx=None, weights=None,
         check(lib.sc_kmeans_fit(ptr(X), _code(X), T, c_int64(D), K, ptr(w), ptr(init), ptr(rs), 0 if rs is None else rs.numel(),
                                 max_iter, c_float(tol), ptr(C), ptr(labels), ptr(wsum), ptr(info), ptr(ws), c_size_t(ws.numel()),
                                 stream_ptr(dev)), "sc_kmeans_fit")
+    if KernelTimer.active is not None:
+        KernelTimer.active.aux.setdefault("kmeans_info", []).append(info)
     return C, labels, wsum, info
 
 

@@ -1,0 +1,235 @@
+"""Sharded memory update with SINGLE-STREAM semantics.
+
+One process per GPU.  The frames of a segment are dealt to the ranks by whole chunks (`dist.partition_chunks`); every rank
+encodes and captions its own chunks.  Everything the reference decides on the GLOBAL stream is decided here on the global stream
+too, from metadata that is identical on every rank:
+
+  * short-term memory: forgetting-curve sampling over the last `short_window` frames of the segment
+    (/root/reference/inference_streaming_longva_v2.py:319-337) -> global frame numbers, same RNG draw on every rank;
+  * long-term memory: ALL new depth-0 nodes are appended to the ONE tree, then at most ONE merge of the first `interval` siblings
+    of the highest eligible depth (/root/reference/utiles.py:525-536,567-620 via `utiles.plan_merge`) — not one merge per rank;
+  * the merge-group k-means runs ONCE, on the rank that owns the group's first row (the rows another rank holds are sent to it
+    point to point), with the init rows every rank drew from the same CPU generator: labels / centroids are those of the 1-GPU run.
+
+A tree node's `.centroids` is a `Ref` — a list of (owner rank, store key, row range) — instead of a tensor; tensors stay where they
+were produced until `fetch` moves exactly the selected rows (short-memory frames + retrieved nodes) to the consumer: ONE
+`all_gather_into_tensor` of a right-sized buffer (every rank derives the per-rank row counts from the same metadata, so there is
+no size exchange and no capacity guess), after which rank 0 owns the [short | long] block for the single-GPU 7B prefill.
+Frame ranges are never exchanged: they follow from `partition_chunks`.  With world size 1 every `fetch` is a view.
+
+The retrieved-frame indices, tree shape and texts therefore do not depend on the number of GPUs
+(tests/test_sharded_gloo.py: world 2 and 4 == the single-stream `updating_memory_buffer` on the same stream)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import utiles as U
+from .dist import broadcast_object, gather_objects, partition_chunks
+
+BANK, MERGE = 0, 1          # store key kinds: ("bank", segment) frame features / ("merge", node id) k-means centroids
+
+
+class Ref:
+    """Rows of a logical [rows, P, D] tensor scattered over ranks: pieces = ((owner, kind, id, lo, hi), ...) in row order."""
+    __slots__ = ("pieces",)
+
+    def __init__(self, pieces):
+        self.pieces = tuple(tuple(int(x) for x in p) for p in pieces if p[4] > p[3])
+
+    @property
+    def rows(self):
+        return sum(p[4] - p[3] for p in self.pieces)
+
+    @property
+    def shape(self):                        # the builder's `combined_centroids.shape[0] > num_clusters` test (utiles.py:586)
+        return (self.rows,)
+
+    @staticmethod
+    def concat(refs):
+        return Ref([p for r in refs for p in r.pieces])
+
+    def __eq__(self, o):
+        return isinstance(o, Ref) and self.pieces == o.pieces
+
+    def __repr__(self):
+        return f"Ref{self.pieces}"
+
+
+class ShardedMemory:
+    def __init__(self, ctx, chunk_size=30, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5):
+        self.ctx = ctx
+        self.chunk_size, self.num_clusters, self.interval = chunk_size, num_clusters, interval
+        self.short_window, self.remember_window, self.tau = short_window, remember_window, tau
+        self.store = {}             # (kind, id) -> local tensor [rows, P, D]
+        self.seg_parts = []         # per segment: [(start, end)] per rank (segment-local frame numbers)
+        self.tree = None
+        self.next_node = 0
+        self.row_shape = None       # (P, D), dtype, device of a feature row
+        self._send = self._recv = None
+
+    # ---------------------------------------------------------------------------------------------
+    def partition(self, n_frames):
+        return partition_chunks(n_frames, self.chunk_size, self.ctx.world)
+
+    def frame_ref(self, seg, a, b):
+        """frames [a, b) of segment `seg` (segment-local numbering) -> Ref (split at rank boundaries)."""
+        out = []
+        for r, (x, y) in enumerate(self.seg_parts[seg]):
+            lo, hi = max(a, x), min(b, y)
+            if hi > lo:
+                out.append((r, BANK, seg, lo - x, hi - x))
+        return Ref(out)
+
+    def frames_of(self, ref):
+        """global description of a Ref's frame rows: [(segment, frame)] for BANK pieces, (MERGE, node, row) otherwise (tests / logs)."""
+        out = []
+        for (r, kind, i, lo, hi) in ref.pieces:
+            base = self.seg_parts[i][r][0] if kind == BANK else 0
+            out += [("frame", i, base + f) if kind == BANK else ("centroid", i, f) for f in range(lo, hi)]
+        return out
+
+    # ---------------------------------------------------------------------------------------------
+    def update(self, local_feats, n_frames, summarizer_model, summarizer_tokenzier, rng=None):
+        """One memory update over a new segment of `n_frames` frames (the sharded `updating_memory_buffer`,
+        inference_streaming_longva_v2.py:267-378).  `local_feats` [n_local, P, D]: this rank's frames, i.e. frames
+        `self.partition(n_frames)[rank]` of the segment.  Returns (tree, short) with Refs in place of tensors."""
+        from .streaming import _captioning_ids
+        ctx, cs = self.ctx, self.chunk_size
+        parts = self.partition(n_frames)
+        a, b = parts[ctx.rank]
+        if local_feats.shape[0] != b - a:
+            raise ValueError(f"rank {ctx.rank} owns frames [{a}, {b}) of this segment but was given {local_feats.shape[0]} rows")
+        seg = len(self.seg_parts)
+        self.seg_parts.append(parts)
+        self.store[(BANK, seg)] = local_feats
+        if self.row_shape is None:
+            self.row_shape = (tuple(local_feats.shape[1:]), local_feats.dtype, local_feats.device)
+
+        # ---- short-term memory: the same draw on every rank, over global frame numbers (:319-337) ----
+        window = min(self.short_window, n_frames)
+        fifo = list(range(n_frames - window, n_frames))
+        probs = U.calculate_forgetting_probabilities(window, tau=self.tau)
+        short = [self.frame_ref(seg, f, f + 1) for f in
+                 U.select_data_without_replacement(fifo, probs, min(self.remember_window, window), rng=rng)]
+
+        # ---- captions of the local chunks, exchanged as text (once per update) ----
+        ids = _captioning_ids(summarizer_model, summarizer_tokenzier)
+        mine = [U.caption_chunk(summarizer_model, summarizer_tokenzier, ids, local_feats[s:s + cs]) for s in range(0, b - a, cs)]
+        captions = [c for part in gather_objects(ctx, mine) for c in part]
+        n_chunks = (n_frames + cs - 1) // cs
+        assert len(captions) == n_chunks, (len(captions), n_chunks)
+        nodes = [U.MultimodalTreeNode(self.frame_ref(seg, c * cs, min((c + 1) * cs, n_frames)), captions[c], depth=0) for c in range(n_chunks)]
+        if self.tree:
+            nodes = self.tree + nodes
+
+        # ---- at most ONE merge on the global node list (utiles.py:567-620) ----
+        start = U.plan_merge(nodes, self.interval)
+        if start is not None:
+            group = nodes[start:start + self.interval]
+            combined = Ref.concat([n.centroids for n in group])
+            executor = combined.pieces[0][0]
+            if combined.rows > self.num_clusters:
+                # every rank draws the init rows (keeps the CPU generator in lockstep with the 1-GPU run); only the executor clusters
+                init_idx = torch.randperm(combined.rows)[:self.num_clusters]
+                X = self.fetch([combined], dst=executor, mode="p2p")
+                node_id = self.next_node
+                self.next_node += 1
+                if ctx.rank == executor:
+                    new_centroids, _ = U.weighted_kmeans_feature(X, self.num_clusters, init_idx=init_idx)
+                    self.store[(MERGE, node_id)] = new_centroids
+                new_ref = Ref([(executor, MERGE, node_id, 0, self.num_clusters)])
+            else:
+                new_ref = combined
+            text = None
+            if ctx.rank == executor:
+                text = U.summarize_captions(summarizer_model, summarizer_tokenzier, [n.text for n in group])
+            text = broadcast_object(ctx, text, src=executor)
+            new_node = U.MultimodalTreeNode(new_ref, text, depth=group[0].depth + 1)
+            new_node.children.extend(group)
+            nodes[start:start + self.interval] = [new_node]
+        self.tree = nodes
+        return nodes, short
+
+    # ---------------------------------------------------------------------------------------------
+    def _local(self, piece):
+        _, kind, i, lo, hi = piece
+        return self.store[(kind, i)][lo:hi]
+
+    def fetch(self, refs, dst=0, mode="allgather"):
+        """Rows of `refs` (in order) as ONE [rows, P, D] tensor on rank `dst` (None elsewhere).  `refs` must be identical on every
+        rank.  mode "allgather": one all_gather_into_tensor of max-rows-per-rank (the selected features of a question);
+        mode "p2p": owners send their pieces straight to dst (the merge group when it straddles ranks)."""
+        ctx = self.ctx
+        pieces = [p for r in refs for p in r.pieces]
+        if ctx.world == 1:
+            return U.cat_frames([self._local(p) for p in pieces])                    # adjacent bank rows: a view, no copy
+        (P, D), dtype, dev = self.row_shape
+        total = sum(p[4] - p[3] for p in pieces)
+        if all(p[0] == dst for p in pieces):                                         # nothing to move (e.g. C4's first ten chunks)
+            return U.cat_frames([self._local(p) for p in pieces]) if ctx.rank == dst else None
+        if mode == "p2p":
+            ops, out, off = [], None, 0
+            if ctx.rank == dst:
+                out = torch.empty((total, P, D), dtype=dtype, device=dev)
+            for p in pieces:
+                n = p[4] - p[3]
+                if ctx.rank == dst:
+                    if p[0] == dst:
+                        out[off:off + n].copy_(self._local(p))
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, out[off:off + n], p[0]))
+                elif p[0] == ctx.rank:
+                    ops.append(dist.P2POp(dist.isend, self._local(p).contiguous(), dst))
+                off += n
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return out
+        # ---- all-gather: rank r packs its pieces (in order) into slot r of a [world, cap] buffer ----
+        counts = [0] * ctx.world
+        for p in pieces:
+            counts[p[0]] += p[4] - p[3]
+        cap = max(counts)
+        if self._send is None or self._send.shape[0] < cap:
+            self._send = torch.empty((cap, P, D), dtype=dtype, device=dev)
+            self._recv = torch.empty((ctx.world * cap, P, D), dtype=dtype, device=dev)
+        send, recv = self._send[:cap], self._recv[:ctx.world * cap]
+        k = 0
+        for p in pieces:
+            if p[0] == ctx.rank:
+                n = p[4] - p[3]
+                send[k:k + n].copy_(self._local(p))
+                k += n
+        dist.all_gather_into_tensor(recv, send)                  # RCCL: every peer pushes its slot over its own xGMI link
+        if ctx.rank != dst:
+            return None
+        slot, views = [0] * ctx.world, []
+        for p in pieces:
+            n = p[4] - p[3]
+            views.append(recv[p[0] * cap + slot[p[0]]: p[0] * cap + slot[p[0]] + n])
+            slot[p[0]] += n
+        return U.cat_frames(views) if len(views) == 1 else torch.cat(views, dim=0)
+
+    # ---------------------------------------------------------------------------------------------
+    def broadcast_refs(self, refs, src=0, capacity=64):
+        """The root's retrieval decision (a list of Refs) to every rank as ONE small int64 tensor broadcast (no pickling):
+        rows = (ref index, owner, kind, id, lo, hi), -1 padded."""
+        ctx = self.ctx
+        if ctx.world == 1:
+            return refs
+        dev = self.row_shape[2]
+        buf = torch.full((capacity, 6), -1, dtype=torch.int64)
+        if ctx.rank == src:
+            rows = [(i,) + p for i, r in enumerate(refs) for p in r.pieces]
+            if len(rows) > capacity:
+                raise ValueError(f"{len(rows)} pieces exceed the broadcast capacity {capacity}")
+            if rows:
+                buf[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+        buf = buf.to(dev)
+        dist.broadcast(buf, src=src)
+        rows = buf.cpu().tolist()
+        out = {}
+        for i, *p in rows:
+            if i >= 0:
+                out.setdefault(i, []).append(tuple(p))
+        return [Ref(out[i]) for i in sorted(out)]

@@ -177,6 +177,42 @@ def get_summarize_depth(nodes, interval):
     return 0, depth_count
 
 
+def plan_merge(nodes, interval):
+    """Merge decision of utiles.py:567-574 on a top-level node list: index of the first node of the `interval` siblings to merge,
+    or None.  Pure metadata (depths only) — shared by the single-stream builder below and the sharded one (sharded.py), so both
+    take the same decision on the same global node list."""
+    if len(nodes) == 0:
+        return None
+    summarize_depth, _ = get_summarize_depth(nodes, interval)
+    start_index = next((index for index, node in enumerate(nodes) if node.depth == summarize_depth), None)
+    chunk_length = len([x for x in nodes if x.depth == summarize_depth])
+    _log("summarize_depth:{}/ start_index:{}/ chunk_length:{} / len(nodes):{}".format(summarize_depth, start_index, chunk_length, len(nodes)))
+    return start_index if chunk_length >= interval else None
+
+
+def caption_chunk(summarizer, tokenizer, input_ids, chunk_feature):
+    """One chunk caption (utiles.py:539-559): the chunk's frames as image tokens, 128 new tokens, temperature 0.1.
+    `chunk_feature`: list of [1, P, D] frame tensors or one [n, P, D] tensor."""
+    if isinstance(chunk_feature, (list, tuple)):
+        chunk_feature = cat_frames(chunk_feature)
+    chunk_feature = chunk_feature.reshape(-1, chunk_feature.shape[-1]).to(summarizer.device)
+    with torch.no_grad():
+        output_ids = summarizer.generate_with_image_embedding(
+            input_ids.to(summarizer.device), image_embeddings=[chunk_feature], modalities=["video"],
+            do_sample=True, temperature=0.1, top_p=None, max_new_tokens=128, use_cache=False)
+    return tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+
+
+def summarize_captions(summarizer, tokenizer, caption_list, conv_templates=None):
+    """Summary text of a merge (utiles.py:589-607): text-only prompt, 256 new tokens, temperature 0.1."""
+    summarize_ids = make_summary_prompt(caption_list, tokenizer, conv_templates)
+    with torch.no_grad():
+        output_ids = summarizer.generate_with_image_embedding(
+            summarize_ids.to(summarizer.device), image_embeddings=None, modalities=["video"],
+            do_sample=True, temperature=0.1, top_p=None, max_new_tokens=256, use_cache=False)
+    return tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+
+
 def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_clusters, interval, summarizer, input_ids,
                                               tokenizer, chunked_feature_list, existing_tree=None, conv_templates=None, batch_captions=False):
     """Drop-in for reference utiles.py:489-620: caption every new chunk with the LLM, append depth-0 nodes,
@@ -196,25 +232,14 @@ def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_cl
         output_list = [tokenizer.batch_decode(o, skip_special_tokens=True)[0].strip() for o in outs]
         chunked_feature_list = []
     for chunk_feature in chunked_feature_list:
-        dimension = chunk_feature[0].shape[-1]
-        chunk_feature = cat_frames(chunk_feature).reshape(-1, dimension).to(summarizer.device)
-        with torch.no_grad():
-            output_ids = summarizer.generate_with_image_embedding(
-                input_ids.to(summarizer.device), image_embeddings=[chunk_feature], modalities=["video"],
-                do_sample=True, temperature=0.1, top_p=None, max_new_tokens=128, use_cache=False)
-        outputs = tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
-        output_list.append(outputs)
+        output_list.append(caption_chunk(summarizer, tokenizer, input_ids, chunk_feature))
 
     nodes = [MultimodalTreeNode(tensor, text, depth=0) for (tensor, text) in zip(k_means_chunk_feature_list, output_list)]
     if existing_tree:
         nodes = existing_tree + nodes
 
-    summarize_depth, depth_count = get_summarize_depth(nodes, interval)
-    start_index = next((index for index, node in enumerate(nodes) if node.depth == summarize_depth), None)
-    chunk_length = len([x for x in nodes if x.depth == summarize_depth])
-    _log("summarize_depth:{}/ start_index:{}/ chunk_length:{} / len(nodes):{}".format(summarize_depth, start_index, chunk_length, len(nodes)))
-
-    if chunk_length % interval >= 0 and len(nodes) > 0 and chunk_length >= interval:
+    start_index = plan_merge(nodes, interval)
+    if start_index is not None:
         chunk = nodes[start_index: start_index + interval]
         centroids_list = [node.centroids for node in chunk]
         caption_list = [node.text for node in chunk]
@@ -223,12 +248,7 @@ def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_cl
             new_centroids, labels = weighted_kmeans_feature(combined_centroids, num_clusters)
         else:
             new_centroids = combined_centroids
-        summarize_ids = make_summary_prompt(caption_list, tokenizer, conv_templates)
-        with torch.no_grad():
-            output_ids = summarizer.generate_with_image_embedding(
-                summarize_ids.to(summarizer.device), image_embeddings=None, modalities=["video"],
-                do_sample=True, temperature=0.1, top_p=None, max_new_tokens=256, use_cache=False)
-        summarize_text = tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+        summarize_text = summarize_captions(summarizer, tokenizer, caption_list, conv_templates)
         new_node = MultimodalTreeNode(new_centroids, summarize_text, depth=chunk[0].depth + 1)
         for node in chunk:
             new_node.children.append(node)

@@ -1,0 +1,50 @@
+"""GPU: the sharded (N > 1) code path of bench.py run at world size 1 (`--force-sharded`) must equal the single-GPU step through the
+reference-seam functions on the same stream — same tree, same retrieved frames, bit-identical [short | long] feature block
+(VERDICT r01 item 1).  The multi-rank control flow itself is covered on CPU by tests/test_sharded_gloo.py (gloo, world 2 and 4)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _describe(nodes):
+    def one(n):
+        return dict(depth=n.depth, rows=int(n.centroids.shape[0]), text=n.text, children=[one(c) for c in n.children])
+    return [one(n) for n in nodes]
+
+
+def test_force_sharded_world1_equals_single_gpu_step():
+    import bench
+    dev = torch.device("cuda:0")
+    pipe = bench.Pipeline(dev, 440, with_llm=False)                 # 11 chunks of 40: ten of them merge (k-means T=400, K=5, full D)
+    a = pipe.step()
+    want = torch.cat([t.reshape(-1, t.shape[-1]) for t in list(a["short"]) + list(a["path_feats"])]).clone()
+    tree_a, text_a = _describe(a["tree"]), list(a["path_text"])
+    merged_a = [n.centroids.clone() for n in a["tree"] if n.depth > 0]
+    b = pipe.step_sharded()
+    assert _describe(b["tree"]) == tree_a and list(b["path_text"]) == text_a
+    assert torch.equal(b["image_embeddings"], want)
+    merged_b = [b["mem"].fetch([n.centroids]) for n in b["tree"] if n.depth > 0]
+    assert len(merged_a) == 1 and all(torch.equal(x, y) for x, y in zip(merged_a, merged_b))
+    # retrieved frame indices: 5 short-memory frames of the last 20, then two whole chunks
+    frames = [f for r in b["wanted"] for f in r]
+    assert len(frames) == 5 + 40 + 40 and all(k == "frame" and 420 <= f < 440 for k, _, f in frames[:5])
+
+
+def test_encode_is_independent_of_how_the_stream_is_batched():
+    """What makes the sharded encode P-independent: a frame's features do not depend on which other frames share its
+    micro-batch (every GEMM / attention row is computed with a fixed reduction order)."""
+    import bench
+    dev = torch.device("cuda:0")
+    pipe = bench.Pipeline(dev, 120, with_llm=False)
+    pipe.encode()
+    whole = pipe.feats.clone()
+    for lo, hi in ((0, 40), (40, 47), (47, 119), (119, 120)):                   # a rank owning frames [lo, hi) encodes them on their own
+        part = pipe.enc.encode_frames_u8(pipe.frames[lo:hi])
+        assert torch.equal(part, whole[lo:hi])

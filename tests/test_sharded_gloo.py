@@ -1,0 +1,209 @@
+"""CPU, gloo, world size 2 and 4: the WHOLE sharded memory-update / retrieval control flow (streamchat_amd/sharded.py) against
+the single-stream functions (`streaming.updating_memory_buffer` + `utiles.fast_search_tree_multi_modal_with_embedding`) on the
+same global stream: tree shape and texts, merge centroids, short-memory frames, retrieved ("wanted") frames and the fetched
+feature rows must not depend on the number of ranks (reference policy utiles.py:525-536,567-620,
+chunking inference_streaming_longva_v2.py:346-358).
+
+The k-means / top-k providers are swapped for the ORACLE (test infrastructure) in BOTH runs so that the control flow can run
+without a GPU; tests/test_gpu_sharded.py runs the HIP path through the same code at world size 1."""
+import os
+import socket
+import types
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+P_, D_ = 3, 8
+MEM = dict(chunk_size=4, num_clusters=2, interval=3, short_window=6, remember_window=3, tau=5)
+SEGMENTS = [26, 3, 13, 24, 9]            # frames per update: straddling merges, a segment smaller than the world, a depth-1 merge
+QUESTION = "where is the red cup"
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _segment(seg, n):
+    g = torch.Generator().manual_seed(1000 + seg)
+    base = torch.arange(n, dtype=torch.float32).view(n, 1, 1) // MEM["chunk_size"] * 3.0 + 100.0 * seg
+    return (base + 0.05 * torch.randn(n, P_, D_, generator=g)).contiguous()
+
+
+class Tok:                                   # summarizer-side tokenizer: ids = word hashes, decode = text of the "generated" hash
+    bos_token_id = None
+
+    def __call__(self, text, **kw):
+        return types.SimpleNamespace(input_ids=[zlib.crc32(w.encode()) % 30000 for w in text.split()])
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [f" caption#{int(ids[0][0])} "]
+
+
+class Summarizer:                            # deterministic in its INPUT (content hash), like synthetic.SyntheticCaptioner
+    device = "cpu"
+    config = types.SimpleNamespace(mm_use_im_start_end=False)
+
+    def generate_with_image_embedding(self, ids, image_embeddings=None, **kw):
+        key = (image_embeddings[0].reshape(-1)[:8] if image_embeddings is not None else torch.as_tensor(ids).reshape(-1).float()).numpy().tobytes()
+        return torch.tensor([[zlib.crc32(key) % 100003]])
+
+
+class EmbTok:
+    def __call__(self, text, padding=True, return_tensors="pt"):
+        texts = [text] if isinstance(text, str) else list(text)
+        rows = [[zlib.crc32(t.encode()) % 9973 + 1] for t in texts]
+        return {"input_ids": torch.tensor(rows)}
+
+
+class EmbModel:                               # CLS embedding = seeded pseudo-random vector of the text hash
+    def __call__(self, input_ids=None, **kw):
+        out = torch.stack([torch.randn(1, 16, generator=torch.Generator().manual_seed(int(i))) for i in input_ids[:, 0]])
+        return types.SimpleNamespace(last_hidden_state=out)
+
+
+def _patch_providers():
+    import oracle
+    from streamchat_amd import ops, utiles as U
+
+    def kmeans_feature(img_feature, K, weights=None, *, init_idx=None, **kw):
+        T, P, D = img_feature.shape
+        if init_idx is None:
+            init_idx = torch.randperm(T)[:K]
+        r = oracle.kmeans_fit(img_feature.reshape(T, -1).numpy(), K, np.asarray(init_idx, np.int32), np.zeros(10 * K, np.int32))
+        return torch.from_numpy(r["centroids"]).view(K, P, D), torch.from_numpy(r["labels"])
+
+    def sim_topk(q, docs, k=1, metric="cos"):
+        idx, sc = oracle.topk(q.numpy(), docs.numpy(), k, metric)
+        return torch.from_numpy(idx), torch.from_numpy(sc)
+    U.weighted_kmeans_feature = kmeans_feature
+    ops.sim_topk = sim_topk
+
+
+def _describe(nodes):
+    def one(n):
+        return dict(depth=n.depth, rows=int(n.centroids.shape[0]), text=n.text, children=[one(c) for c in n.children])
+    return [one(n) for n in nodes]
+
+
+def _single_stream():
+    """the reference policy through the single-GPU functions: per update (tree description, short rows, path rows, path texts)"""
+    from streamchat_amd import streaming as S, utiles as U
+    torch.manual_seed(7)
+    rng = np.random.RandomState(11)
+    tree, out = None, []
+    for seg, n in enumerate(SEGMENTS):
+        feats = _segment(seg, n)
+        bank = [feats[i:i + 1] for i in range(n)]
+        tree, short = S.updating_memory_buffer(bank, tree, Summarizer(), Tok(), True, rng=rng, **MEM)
+        path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, QUESTION, feats[0], EmbModel(), EmbTok(), cache=U.CaptionEmbeddingCache())
+        merged = [n.centroids.clone() for n in tree if n.depth > 0]
+        out.append(dict(tree=_describe(tree), short=torch.cat(short), path=torch.cat(path), texts=texts, merged=merged))
+    return out
+
+
+def _sharded(ctx):
+    from streamchat_amd import sharded as SH, utiles as U
+    torch.manual_seed(7)
+    rng = np.random.RandomState(11)
+    mem = SH.ShardedMemory(ctx, **MEM)
+    out = []
+    for seg, n in enumerate(SEGMENTS):
+        a, b = mem.partition(n)[ctx.rank]
+        local = _segment(seg, n)[a:b].contiguous()
+        tree, short = mem.update(local, n, Summarizer(), Tok(), rng=rng)
+        wanted, texts = None, None
+        if ctx.is_root:                                   # retrieval runs on the root only; its decision is broadcast as metadata
+            path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, QUESTION, local, EmbModel(), EmbTok(), cache=U.CaptionEmbeddingCache())
+            wanted = list(short) + list(path)
+        wanted = mem.broadcast_refs(wanted)
+        n_short = len(short)
+        sel = mem.fetch(wanted, dst=0, mode="allgather")
+        merged = [mem.fetch([nd.centroids], dst=0, mode="p2p") for nd in tree if nd.depth > 0]
+        srows = sum(r.rows for r in wanted[:n_short])
+        out.append(dict(tree=_describe(tree), short=None if sel is None else sel[:srows], path=None if sel is None else sel[srows:],
+                        texts=texts, merged=merged, wanted=[mem.frames_of(r) for r in wanted]))
+    return out
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from streamchat_amd import dist as D
+        _patch_providers()
+        ctx = D.init_from_env("cpu")
+        ref = _single_stream()
+        got = _sharded(ctx)
+        ok, why = True, ""
+        for u, (r, g) in enumerate(zip(ref, got)):
+            if r["tree"] != g["tree"]:
+                ok, why = False, f"update {u}: tree differs"
+            if ctx.is_root:
+                if not (torch.equal(r["short"], g["short"]) and torch.equal(r["path"], g["path"]) and r["texts"] == g["texts"]):
+                    ok, why = False, f"update {u}: selected rows / texts differ"
+                if len(r["merged"]) != len(g["merged"]) or not all(torch.equal(x, y) for x, y in zip(r["merged"], g["merged"])):
+                    ok, why = False, f"update {u}: merge centroids differ"
+        q.put((rank, ok, why, [g["wanted"] for g in got]))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:                                  # surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, False, traceback.format_exc(), None))
+        raise
+
+
+def _run_world(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    for rank, ok, why, _ in res:
+        assert ok, f"world {world} rank {rank}: {why}"
+    assert all(r[3] == res[0][3] for r in res)               # every rank holds the same retrieval decision
+    return res[0][3]
+
+
+@pytest.mark.timeout(600)
+def test_sharded_equals_single_stream_world2_and_world4():
+    w2 = _run_world(2)
+    w4 = _run_world(4)
+    assert w2 == w4                                          # identical retrieved (segment, frame) indices for P = 2 and P = 4
+
+
+def test_world1_sharded_memory_is_views_and_equal():
+    """world size 1: the sharded code path IS the single-stream path (no collective, fetch returns views of the bank)."""
+    from streamchat_amd import dist as D, sharded as SH
+    import streamchat_amd.utiles as U
+    import streamchat_amd.ops as ops
+    saved = (U.weighted_kmeans_feature, ops.sim_topk)
+    try:
+        _patch_providers()
+        ref = _single_stream()
+        got = _sharded(D.DistContext(0, 1, "cpu"))
+        for r, g in zip(ref, got):
+            assert r["tree"] == g["tree"] and r["texts"] == g["texts"]
+            assert torch.equal(r["short"], g["short"]) and torch.equal(r["path"], g["path"])
+            assert all(torch.equal(x, y) for x, y in zip(r["merged"], g["merged"]))
+        mem = SH.ShardedMemory(D.DistContext(0, 1, "cpu"), **MEM)
+        feats = _segment(0, 26)
+        tree, short = mem.update(feats, 26, Summarizer(), Tok(), rng=np.random.RandomState(0))
+        leaf = next(n for n in tree if n.depth == 0)
+        assert mem.fetch([leaf.centroids]).data_ptr() == feats[mem.frames_of(leaf.centroids)[0][2]].data_ptr()
+    finally:
+        U.weighted_kmeans_feature, ops.sim_topk = saved
+
+
+def test_ref_algebra_and_partition():
+    from streamchat_amd import dist as D, sharded as SH
+    mem = SH.ShardedMemory(D.DistContext(1, 3, "cpu"), chunk_size=4)
+    mem.seg_parts.append(mem.partition(26))                # 7 chunks over 3 ranks: [0,8) [8,16) [16,26)
+    assert mem.seg_parts[0] == [(0, 8), (8, 16), (16, 26)]
+    r = mem.frame_ref(0, 6, 18)
+    assert r.pieces == ((0, 0, 0, 6, 8), (1, 0, 0, 0, 8), (2, 0, 0, 0, 2)) and r.rows == 12 and r.shape == (12,)
+    assert SH.Ref.concat([mem.frame_ref(0, 0, 2), mem.frame_ref(0, 20, 21)]).pieces == ((0, 0, 0, 0, 2), (2, 0, 0, 4, 5))
+    assert mem.frames_of(mem.frame_ref(0, 15, 17)) == [("frame", 0, 15), ("frame", 0, 16)]
