@@ -70,6 +70,20 @@ int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, const float
 int sc_kmeans_assign(const void* X, int dtype, int T, int64_t D, int K, const float* C,
                      int64_t* labels, double* dist2, void* ws, size_t ws_bytes, sc_stream_t stream);
 
+/* One centroid-update step from given labels — with sc_kmeans_assign the two halves of a Lloyd iteration, for the host-driven
+ * loops of the vendored clustering APIs whose stopping rule / empty-cluster policy differ from weighted_kmeans_feature:
+ * torch_kmeans KMeans._cluster (reference torch_kmeans/clustering/kmeans.py:517-570: mean of the assigned rows, an empty cluster's
+ * centre becomes the zero vector, torch_kmeans/utils/utils.py:66) and kmeans_pytorch.kmeans (kmeans_pytorch/__init__.py:92-107:
+ * an empty cluster takes a random row).
+ *   labels  [T] int64 (device), values in [0, K)         w  [T] fp32 weights or NULL (all 1)
+ *   C_old   [K, D] fp32 centroids the shift is measured against; C_new [K, D] fp32 out (must not alias C_old)
+ *   empty_mode 0: the j-th empty cluster (ascending k) becomes row fill_idx[j] of X (row 0 if j >= n_fill); 1: zero vector
+ *   wsum    [K] fp32 out or NULL: summed weights per cluster;  shift2 [K] fp64 out or NULL: ||C_old[k] - C_new[k]||^2 (SC-KM1 tree)
+ * Same summation order as sc_kmeans_fit (rows of a cluster in ascending order, fp32, no contraction). */
+int sc_kmeans_update(const void* X, int dtype, int T, int64_t D, int K, const float* w, const int64_t* labels,
+                     const float* C_old, int empty_mode, const int32_t* fill_idx, int n_fill, float* C_new,
+                     float* wsum, double* shift2, void* ws, size_t ws_bytes, sc_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Frame preprocessing.  Replaces `process_images` → CLIPImageProcessor.preprocess rescale+normalise
  * (reference utiles.py:71-87) followed by `.to(torch.float16)` (inference_streaming_longva_v2.py:520).

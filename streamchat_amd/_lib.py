@@ -25,6 +25,8 @@ SIGNATURES = {
     "sc_kmeans_fit": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sc_kmeans_assign": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_kmeans_update": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sc_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
     "sc_preprocess_patchify_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p]),
     "sc_gemm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

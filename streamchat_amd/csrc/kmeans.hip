@@ -310,7 +310,7 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
                                                       const int* __restrict__ order, const int* __restrict__ start,
                                                       const float* __restrict__ W, const int* __restrict__ empty_rank,
                                                       const int* __restrict__ reseed_idx, int n_reseed,
-                                                      float* __restrict__ dpart, int T, int64_t D, int K, int64_t nchunks) {
+                                                      float* __restrict__ dpart, int T, int64_t D, int K, int64_t nchunks, int empty_zero) {
     if (st->done) return;
     const float* __restrict__ Cold = st->cur ? Cb : Ca;
     float* __restrict__ Cnew = st->cur ? Ca : Cb;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) cn[e] = cn[e] / Wk;
-        } else {
+        } else if (!empty_zero) {                 // empty_zero: the centre of an empty cluster is the zero vector (torch_kmeans, utils.py:66)
             const int pos = rbase + empty_rank[k];
             int r = 0;
             if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
@@ -403,39 +403,45 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
     }
 }
 
+// per-cluster squared shift totals ||C_k - C'_k||^2 of clusters [kb, kb + kn) from the per-chunk partials (SC-KM1: 32 contiguous chunk
+// segments in fp64, then the segment sums in fp64); result in tot[0..kn) (shared), valid after the trailing barrier
+__device__ __forceinline__ void km_shift_totals(const float* __restrict__ dpart, int K, int kb, int kn, int64_t nchunks, double* segs, double* tot) {
+    const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
+    for (int p = threadIdx.x; p < NSEG * kn; p += blockDim.x) {
+        const int s = p / kn, k = kb + p % kn;
+        int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
+        if (hi > nchunks) hi = nchunks;
+        double a = 0.0;
+        int64_t c = lo;
+        for (; c + 8 <= hi; c += 8) {                 // 8 independent loads in flight, added in ascending chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dpart[(size_t)(c + u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+        for (; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
+        segs[s * 64 + (k - kb)] = a;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kn) {
+        double t = 0.0;
+        for (int s = 0; s < NSEG; ++s) t += segs[s * 64 + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
 // single block: shift = sum_k sqrt(total_k); decide convergence; advance state
 __global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart, KmState* __restrict__ st, int K, int64_t nchunks,
                                                  int iter, int max_iter, float tol, int n_reseed) {
     if (st->done) return;
     __shared__ double segs[NSEG * 64];   // K <= 64 per pass
     __shared__ double tot[64];
-    const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
     double diff = 0.0;
     for (int kb = 0; kb < K; kb += 64) {
         const int kn = (K - kb) < 64 ? (K - kb) : 64;
-        for (int p = threadIdx.x; p < NSEG * kn; p += blockDim.x) {
-            const int s = p / kn, k = kb + p % kn;
-            int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
-            if (hi > nchunks) hi = nchunks;
-            double a = 0.0;
-            int64_t c = lo;
-            for (; c + 8 <= hi; c += 8) {                 // 8 independent loads in flight, added in ascending chunk order
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = dpart[(size_t)(c + u) * K + k];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a += (double)v[u];
-            }
-            for (; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
-            segs[s * 64 + (k - kb)] = a;
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < kn) {
-            double t = 0.0;
-            for (int s = 0; s < NSEG; ++s) t += segs[s * 64 + threadIdx.x];
-            tot[threadIdx.x] = t;
-        }
-        __syncthreads();
+        km_shift_totals(dpart, K, kb, kn, nchunks, segs, tot);
         if (threadIdx.x == 0)
             for (int k = 0; k < kn; ++k) diff += sqrt(tot[k]);
         __syncthreads();
@@ -453,6 +459,26 @@ __global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart
             if (iter == max_iter - 1) { st->done = 1; st->exit_iter = iter; }
         }
     }
+}
+
+// single block: shift2[k] = ||C_k - C'_k||^2 (fp64) for the caller of sc_kmeans_update; W -> wsum
+__global__ __launch_bounds__(256) void km_shift_out(const float* __restrict__ dpart, const float* __restrict__ W, double* __restrict__ shift2,
+                                                    float* __restrict__ wsum, int K, int64_t nchunks) {
+    __shared__ double segs[NSEG * 64];
+    __shared__ double tot[64];
+    for (int kb = 0; kb < K; kb += 64) {
+        const int kn = (K - kb) < 64 ? (K - kb) : 64;
+        km_shift_totals(dpart, K, kb, kn, nchunks, segs, tot);
+        if ((int)threadIdx.x < kn && shift2) shift2[kb + threadIdx.x] = tot[threadIdx.x];
+        __syncthreads();
+    }
+    if (wsum)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) wsum[k] = W[k];
+}
+
+__global__ void km_labels_in(const int64_t* __restrict__ labels, int* __restrict__ labels32, int T, int K) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) { const int64_t l = labels[t]; labels32[t] = (l < 0 || l >= K) ? 0 : (int)l; }
 }
 
 template <typename Tag>
@@ -558,9 +584,9 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
         hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
         if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
-                                    w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch);
+                                    w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
         else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
-                                w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch);
+                                w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
         hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dpart, w.st, K, nch, it, max_iter, tol, n_reseed);
     }
     hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
@@ -581,6 +607,29 @@ int assign_impl(const void* X, int T, int64_t D, int K, const float* C, int64_t*
     hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, dist2, T, K, 0);
     hipLaunchKernelGGL(km_labels_out, dim3((T + 255) / 256), dim3(256), 0, s, w.labels32, labels, T);
     SC_CHECK_LAUNCH("sc_kmeans_assign");
+    return SC_OK;
+}
+
+// one centroid update from given labels: C_new[k] = sum_{t: label t = k} w_t x_t / W_k (rows in ascending order, SC-KM1), an empty
+// cluster takes row fill_idx[its rank among the empty clusters] (empty_mode 0) or the zero vector (empty_mode 1)
+template <typename Tag>
+int update_impl(const void* X, int T, int64_t D, int K, const float* wts, const int64_t* labels, const float* C_old, int empty_mode,
+                const int32_t* fill_idx, int n_fill, float* C_new, float* wsum, double* shift2, void* ws, hipStream_t s) {
+    KmWs w = carve(ws, T, D, K);
+    const int64_t nch = (D + CH - 1) / CH;
+    const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(C_old) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(C_new) & 15) == 0);
+    hipLaunchKernelGGL(km_set_state, dim3(1), dim3(1), 0, s, w.st, 0);
+    hipLaunchKernelGGL(km_labels_in, dim3((T + 255) / 256), dim3(256), 0, s, labels, w.labels32, T, K);
+    hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 0);
+    const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
+    float* Ca = const_cast<float*>(C_old);        // state.cur == 0: Ca is read (old centroids), Cb written
+    if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, Ca, C_new, w.st, wts, w.order, w.start, w.W, w.empty_rank,
+                                fill_idx, n_fill, w.dpart, T, D, K, nch, empty_mode);
+    else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, Ca, C_new, w.st, wts, w.order, w.start, w.W, w.empty_rank,
+                            fill_idx, n_fill, w.dpart, T, D, K, nch, empty_mode);
+    hipLaunchKernelGGL(km_shift_out, dim3(1), dim3(256), 0, s, w.dpart, w.W, shift2, wsum, K, nch);
+    SC_CHECK_LAUNCH("sc_kmeans_update");
     return SC_OK;
 }
 
@@ -607,6 +656,26 @@ extern "C" int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, 
         case SC_F32: return fit_impl<ScF32>(X, T, D, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C, labels, wsum, info, ws, s);
     }
     return sc_fail(SC_ERR_ARG, "sc_kmeans_fit: unknown dtype %d", dtype);
+}
+
+extern "C" int sc_kmeans_update(const void* X, int dtype, int T, int64_t D, int K, const float* w, const int64_t* labels, const float* C_old,
+                                int empty_mode, const int32_t* fill_idx, int n_fill, float* C_new, float* wsum, double* shift2, void* ws,
+                                size_t ws_bytes, sc_stream_t stream) {
+    SC_REQUIRE(X && labels && C_old && C_new && ws, "sc_kmeans_update: null pointer argument");
+    SC_REQUIRE(T > 0 && D > 0 && K > 0, "sc_kmeans_update: T, D, K must be positive");
+    SC_REQUIRE(C_old != C_new, "sc_kmeans_update: C_new must not alias C_old");
+    SC_REQUIRE(empty_mode == 0 || empty_mode == 1, "sc_kmeans_update: empty_mode must be 0 (fill rows) or 1 (zero vector)");
+    SC_REQUIRE(n_fill >= 0 && (n_fill == 0 || fill_idx), "sc_kmeans_update: n_fill > 0 needs fill_idx");
+    if (ws_bytes < sc_kmeans_workspace_bytes(T, D, K))
+        return sc_fail(SC_ERR_WORKSPACE, "sc_kmeans_update: workspace %zu < required %zu", ws_bytes, sc_kmeans_workspace_bytes(T, D, K));
+    SC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "sc_kmeans_update: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case SC_F16: return update_impl<ScF16>(X, T, D, K, w, labels, C_old, empty_mode, fill_idx, n_fill, C_new, wsum, shift2, ws, s);
+        case SC_BF16: return update_impl<ScBF16>(X, T, D, K, w, labels, C_old, empty_mode, fill_idx, n_fill, C_new, wsum, shift2, ws, s);
+        case SC_F32: return update_impl<ScF32>(X, T, D, K, w, labels, C_old, empty_mode, fill_idx, n_fill, C_new, wsum, shift2, ws, s);
+    }
+    return sc_fail(SC_ERR_ARG, "sc_kmeans_update: unknown dtype %d", dtype);
 }
 
 extern "C" int sc_kmeans_assign(const void* X, int dtype, int T, int64_t D, int K, const float* C, int64_t* labels, double* dist2,

@@ -1,12 +1,13 @@
-"""Multi-GPU layer: the frame stream shards by WHOLE CHUNKS across the GPUs of one node (one process per GPU,
+"""Multi-GPU primitives: the frame stream shards by WHOLE CHUNKS across the GPUs of one node (one process per GPU,
 `torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" on CPU for tests).
 
-What crosses the fabric: frame encode, chunk captioning and the chunk-group k-means are rank-local
-(data parallel, no data-path collective); the reference's stages that need a global view are text-only (tree search over
-captions, dialogue memory) and run on rank 0 from all-gathered node METADATA.  Only the SELECTED frame features (short-term
-memory frames + the retrieved nodes) move: one fixed-capacity `all_gather` (each peer pushes its slice over its own xGMI
-link), after which rank 0 owns the [short | long] token block for the single-GPU 7B prefill.  Nothing here touches label /
-centroid arithmetic, so k-means results do not depend on the number of GPUs."""
+What crosses the fabric: frame encode and chunk captioning are rank-local (data parallel, no data-path
+collective); every decision the reference takes on the whole stream (short-memory draw, tree policy, the ONE merge-group
+k-means, tree search, dialogue memory) is taken on the whole stream here too, from metadata that is identical on every
+rank — see sharded.py, which owns the data movement (point-to-point rows of a merge group that straddles ranks, ONE
+right-sized `all_gather_into_tensor` of the selected features before the single-GPU 7B prefill).  This module holds the
+process-group set-up, the chunk partition (frame ranges follow from it: they are never exchanged) and the two small
+object collectives used for TEXT (chunk captions once per update, the summary text of a merge)."""
 import os
 
 import torch
@@ -74,36 +75,3 @@ def broadcast_object(ctx, obj, src=0):
     box = [obj]
     dist.broadcast_object_list(box, src=src)
     return box[0]
-
-
-def gather_selected_frames(ctx, local_bank, local_range, wanted, capacity):
-    """All-gather of selected frame features.
-      local_bank  [n_local, P, D] features of frames local_range = (start, end) (global indices)
-      wanted      list of global frame indices, identical on every rank (decided by rank 0 and broadcast)
-      capacity    max frames any single rank contributes (fixed-size collective, identical on every rank)
-    Returns [len(wanted), P, D] in `wanted` order on every rank (rank 0 is the consumer)."""
-    a, b = local_range
-    ranges = gather_objects(ctx, (a, b))
-    # slot of every wanted frame: (owner rank, k-th frame that owner contributes) — computed identically on every rank, so an
-    # over-capacity request fails everywhere BEFORE the collective (no rank is left waiting inside all_gather)
-    counters, slots = [0] * ctx.world, []
-    for f in wanted:
-        r = next((i for i, (x, y) in enumerate(ranges) if x <= f < y), None)
-        if r is None:
-            raise IndexError(f"frame {f} is owned by no rank")
-        slots.append((r, counters[r]))
-        counters[r] += 1
-    if max(counters, default=0) > capacity:
-        raise ValueError(f"a rank would send {max(counters)} frames > capacity {capacity}")
-    mine = [f for f in wanted if a <= f < b]
-    P, D = local_bank.shape[1], local_bank.shape[2]
-    buf = torch.zeros((capacity, P, D), dtype=local_bank.dtype, device=local_bank.device)
-    if mine:
-        idx = torch.tensor([f - a for f in mine], device=local_bank.device)
-        buf[: len(mine)] = local_bank.index_select(0, idx)
-    if ctx.world == 1:
-        gathered = [buf]
-    else:
-        gathered = [torch.empty_like(buf) for _ in range(ctx.world)]
-        dist.all_gather(gathered, buf)                      # NCCL/RCCL: each peer pushes its slice over its own xGMI link
-    return torch.stack([gathered[r][k] for r, k in slots]) if slots else buf[:0]

@@ -143,6 +143,31 @@ def kmeans_assign(X: torch.Tensor, C: torch.Tensor, return_dist2: bool = False):
     return (labels, d2) if return_dist2 else labels
 
 
+def kmeans_update(X: torch.Tensor, labels: torch.Tensor, C_old: torch.Tensor, weights=None, empty="zero", fill_idx=None):
+    """One centroid update from given labels (C ABI sc_kmeans_update): returns (C_new [K, D] fp32, wsum [K] fp32, shift2 [K] fp64 =
+    ||C_old[k] - C_new[k]||^2).  empty="zero": an empty cluster's centre is the zero vector (torch_kmeans); empty="fill": the j-th
+    empty cluster takes row fill_idx[j] of X (kmeans_pytorch)."""
+    _require_cuda(X, labels, C_old)
+    lib = _lib.load()
+    X = X.contiguous()
+    T, D = X.shape
+    C_old = C_old.to(torch.float32).contiguous()
+    K = C_old.shape[0]
+    dev = X.device
+    labels = labels.to(device=dev, dtype=torch.int64).contiguous()
+    w = None if weights is None else weights.to(device=dev, dtype=torch.float32).contiguous()
+    fi = None if fill_idx is None else torch.as_tensor(fill_idx, dtype=torch.int32).to(dev).contiguous()
+    C = torch.empty((K, D), dtype=torch.float32, device=dev)
+    wsum = torch.empty(K, dtype=torch.float32, device=dev)
+    shift2 = torch.empty(K, dtype=torch.float64, device=dev)
+    ws = _workspace(lib.sc_kmeans_workspace_bytes(T, D, K), dev)
+    with torch.cuda.device(dev):
+        check(lib.sc_kmeans_update(ptr(X), _code(X), T, c_int64(D), K, ptr(w), ptr(labels), ptr(C_old), 1 if empty == "zero" else 0, ptr(fi),
+                                   0 if fi is None else fi.numel(), ptr(C), ptr(wsum), ptr(shift2), ptr(ws), c_size_t(ws.numel()), stream_ptr(dev)),
+              "sc_kmeans_update")
+    return C, wsum, shift2
+
+
 # ------------------------------------------------------------------------------------------------
 def _f3(v):
     return (c_float * 3)(*[float(x) for x in v])

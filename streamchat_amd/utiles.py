@@ -356,6 +356,23 @@ def fast_search_tree_multi_modal_with_embedding(all_nodes, query, image_embeddin
     return path_features, path_text
 
 
+def search_tree(node, query, top_k=1):
+    """Drop-in for reference utiles.py:909-935 (caller: inference_streaming_longva_v2.py:124, the non-multimodal answer path):
+    walk from `node` (a TreeNode) to a leaf and return the `.centroids` of every visited node, root and leaf included.
+
+    Upstream scores each child with `(query @ child.centroids.view(-1, d).T).sum()` and keeps the smaller one, but BOTH arms of
+    its `if distance < best_distance: ... else: best_child_index = i` assign the loop index, so the child it descends into is
+    always the LAST one, whatever the scores are (NaN included).  The scores therefore cannot influence the result and are not
+    computed here; the golden fixture tests/golden/search_tree.json (the reference function's own output) pins this."""
+    path_features = []
+    current_node = node
+    while current_node.children:
+        path_features.append(current_node.centroids)
+        current_node = current_node.children[len(current_node.children) - 1]
+    path_features.append(current_node.centroids)
+    return path_features
+
+
 # ------------------------------------------------------------------------------------------------
 # dialogue-memory prompt glue (reference utiles.py:1057-1078)
 # ------------------------------------------------------------------------------------------------

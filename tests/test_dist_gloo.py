@@ -1,8 +1,8 @@
-"""CPU, world_size = 2, gloo: the multi-GPU layer (chunk partition, metadata gather, fixed-capacity feature all-gather)."""
+"""CPU, world_size = 2, gloo: the multi-GPU primitives (chunk partition, text collectives, the two row-movement modes of
+sharded.ShardedMemory.fetch with provenance-carrying features).  The whole sharded control flow is in test_sharded_gloo.py."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -25,27 +25,39 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from streamchat_amd import sharded as SH
     ctx = D.init_from_env("cpu")
     n, chunk, P, Dm = 200, 40, 3, 8
-    parts = D.partition_chunks(n, chunk, world)
+    mem = SH.ShardedMemory(ctx, chunk_size=chunk)
+    parts = mem.partition(n)
     a, b = parts[rank]
     # feature of global frame f = f everywhere, so the consumer can check provenance
     bank = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1).expand(b - a, P, Dm).contiguous()
-    metas = D.gather_objects(ctx, dict(rank=rank, frames=(a, b), captions=[f"clip {c}" for c in range(a // chunk, (b + chunk - 1) // chunk)]))
-    wanted = D.broadcast_object(ctx, [199, 3, 120, 121, 40, 0] if rank == 0 else None)
-    got = D.gather_selected_frames(ctx, bank, (a, b), wanted, capacity=8)
-    ok = got.shape == (len(wanted), P, Dm) and got[:, 0, 0].tolist() == [float(f) for f in wanted]
-    ok = ok and [m["rank"] for m in metas] == list(range(world)) and metas[0]["frames"][0] == 0 and metas[-1]["frames"][1] == n
-    try:
-        D.gather_selected_frames(ctx, bank, (a, b), list(range(0, 9)), capacity=8)
-        over = False
-    except ValueError:
-        over = True
-    q.put((rank, ok, over))
+    mem.seg_parts.append(parts)
+    mem.store[(SH.BANK, 0)] = bank
+    mem.row_shape = ((P, Dm), bank.dtype, bank.device)
+    metas = D.gather_objects(ctx, dict(rank=rank, captions=[f"clip {c}" for c in range(a // chunk, (b + chunk - 1) // chunk)]))
+    ok = [m["rank"] for m in metas] == list(range(world)) and [c for m in metas for c in m["captions"]] == [f"clip {c}" for c in range(5)]
+    wanted_frames = [199, 3, 120, 121, 40, 0]
+    refs = [mem.frame_ref(0, f, f + 1) for f in wanted_frames] + [mem.frame_ref(0, 70, 130)]        # the last one straddles both ranks
+    refs = mem.broadcast_refs(refs if rank == 0 else None)
+    expect = [float(f) for f in wanted_frames] + [float(f) for f in range(70, 130)]
+    for mode in ("allgather", "p2p"):
+        for dst in (0, 1):
+            got = mem.fetch(refs, dst=dst, mode=mode)
+            if rank == dst:
+                ok = ok and got.shape == (len(expect), P, Dm) and got[:, 0, 0].tolist() == expect and bool((got == got[:, :1, :1]).all())
+            else:
+                ok = ok and got is None
+    only0 = mem.fetch([mem.frame_ref(0, 0, 80)], dst=0)                    # rows already on dst: no collective, a view of the bank
+    ok = ok and ((only0.data_ptr() == bank.data_ptr()) if rank == 0 else only0 is None)
+    ok = ok and D.broadcast_object(ctx, "summary" if rank == 1 else None, src=1) == "summary"
+    q.put((rank, ok))
+    torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_gather_selected_frames_world2_gloo():
+def test_fetch_modes_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -54,11 +66,3 @@ def test_gather_selected_frames_world2_gloo():
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(timeout=60) for p in ps]
     assert [r[1] for r in res] == [True, True]
-    assert res[0][2] is True and res[1][2] is True                    # over-capacity request fails on EVERY rank, before the collective
-
-
-def test_world1_is_identity():
-    ctx = D.DistContext(0, 1, "cpu")
-    bank = torch.arange(10, dtype=torch.float32).view(10, 1, 1).expand(10, 2, 4).contiguous()
-    got = D.gather_selected_frames(ctx, bank, (0, 10), [7, 2], capacity=4)
-    assert got[:, 0, 0].tolist() == [7.0, 2.0]
