@@ -202,6 +202,19 @@ int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void*
                      const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
                      int o_head_stride, int64_t q_batch_stride, int64_t o_batch_stride, sc_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Next-token selection over fp32 LM-head logits.  Replaces what HF `generate` does after the forward pass
+ * (reference llava_qwen.py:155 -> transformers GenerationMixin: argmax when do_sample=False; temperature softmax +
+ * multinomial when do_sample=True — inference_streaming_longva_v2.py:252-253 temperature 0.2, utiles.py:551-552 0.1).
+ *   logits [B, ld] fp32 rows of V valid entries;  out [B] int64 (device)
+ *   temperature <= 0: arg-max, lowest index among equal maxima.
+ *   temperature  > 0: sample from softmax(logits / temperature) by inverting the CDF at u[b] in [0, 1) (device floats the
+ *                     caller draws, e.g. from a torch generator: the draw, not the kernel, carries the randomness).
+ *   ws: sc_pick_token_workspace_bytes(B) bytes.  Two launches, no host synchronisation (hipGraph-capturable). */
+size_t sc_pick_token_workspace_bytes(int B);
+int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out,
+                      void* ws, size_t ws_bytes, sc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

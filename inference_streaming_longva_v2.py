@@ -7,9 +7,15 @@ The functions it drives keep the reference's names (streamchat_amd.streaming / u
 them runs on hand-written gfx950 kernels.  Differences: ONE model replica serves both answering and chunk captioning (the
 reference loads two 7B copies on cuda:0 / cuda:1, :697-700); generation uses a KV cache.
 
-Offline operation: `--synthetic N` runs N synthetic videos (seeded scene-structured frames, random-init weights of the real
-architectures, hash tokenizers) — there are no checkpoints or datasets in this environment.  With real checkpoints pass
-`--model_name` (LongVA-7B state dict directory) and `--embedding_model_id`; see INTEGRATION.md §A."""
+Two modes:
+  * real run (default): `--model_name` is a LongVA-7B checkpoint directory in HF format (config.json, sharded safetensors / .bin,
+    tokenizer), `--embedding_model_id` the mxbai-colbert-large-v1 directory (reference :703-705), `--sentence_model_id` the
+    all-MiniLM-L6-v2 directory behind the dialogue memory (local_doc_qa.py:193), `--vision_tower` the CLIP directory when the
+    checkpoint does not carry the tower.  They are loaded by streamchat_amd/checkpoint.py (what load_pretrained_model,
+    longva/model/builder.py:27-285, does upstream); a missing or unreadable checkpoint is an ERROR, never a silent random init.
+    Frames of any resolution are resized + centre-cropped on the host like CLIPImageProcessor does (utiles.py:71-87).
+  * `--synthetic N`: N synthetic videos (seeded scene-structured frames, random-init weights of the real architectures, hash
+    tokenizers) — there are no checkpoints or datasets in this environment."""
 import argparse
 import json
 import os
@@ -57,7 +63,9 @@ def parse_args(argv=None):
     p.add_argument("--multi_modal_memory", action="store_true", help="weather to open multi-modal memory")
     # additions
     p.add_argument("--synthetic", type=int, default=0, help="run N synthetic videos instead of --annotations / --video_dir")
-    p.add_argument("--embedding_model_id", type=str, default=None, help="mxbai-colbert-large-v1 checkpoint (reference :703)")
+    p.add_argument("--embedding_model_id", type=str, default=None, help="mxbai-colbert-large-v1 checkpoint directory (reference :703)")
+    p.add_argument("--sentence_model_id", type=str, default=None, help="all-MiniLM-L6-v2 directory (dialogue-memory embedder, local_doc_qa.py:193)")
+    p.add_argument("--vision_tower", type=str, default=None, help="CLIP ViT-L/14-336 directory if the LongVA checkpoint carries no tower weights")
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
     p.add_argument("--max_new_tokens", type=int, default=256)
     p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
@@ -77,21 +85,34 @@ class SyntheticCapture:
 
 
 class Cv2Capture:
-    def __init__(self, path):
+    """cv2.VideoCapture adapter: seek + decode + BGR->RGB (reference :503-511), then the resize / centre-crop half of
+    CLIPImageProcessor.preprocess on the host (utiles.py:71-87); rescale + normalise are fused into the GPU patch gather."""
+    def __init__(self, path, image_size=336):
         import cv2                                           # host decode stays on the CPU (out of the GPU hot path)
-        self.cv2, self.cap = cv2, cv2.VideoCapture(path)
+        self.cv2, self.cap, self.image_size = cv2, cv2.VideoCapture(path), image_size
         self.n = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
         self.fps = int(self.cap.get(cv2.CAP_PROP_FPS))
 
     def read_rgb(self, i):
+        from streamchat_amd.mm_utils import resize_center_crop_u8
         self.cap.set(self.cv2.CAP_PROP_POS_FRAMES, i)
         ret, frame = self.cap.read()
-        return self.cv2.cvtColor(frame, self.cv2.COLOR_BGR2RGB) if ret else None
+        return resize_center_crop_u8(self.cv2.cvtColor(frame, self.cv2.COLOR_BGR2RGB), self.image_size) if ret else None
 
 
 def build_models(args):
-    """Random-init models of the real (or --tiny) architectures.  Loading real checkpoints: INTEGRATION.md §A."""
+    """Real checkpoints (default) or, with --synthetic, random-init models of the real (or --tiny) architectures."""
     dev = args.device
+    if not args.synthetic:
+        from streamchat_amd import checkpoint as CK
+        missing = [f for f, v in (("--embedding_model_id", args.embedding_model_id), ("--sentence_model_id", args.sentence_model_id)) if not v]
+        if missing:
+            raise SystemExit(f"a real run needs {', '.join(missing)} (checkpoint directories); use --synthetic N for random-init smoke runs")
+        model, tokenizer, vc = CK.load_longva(args.model_name, device=dev, vision_tower_path=args.vision_tower)
+        embedding_model, embedding_tokenizer = CK.load_bert(args.embedding_model_id, device=dev)
+        minilm, minilm_tok = CK.load_bert(args.sentence_model_id, device=dev)
+        sentence = HipSentenceEmbeddings(T.SentenceEmbedder(minilm), minilm_tok)
+        return model, tokenizer, embedding_model, embedding_tokenizer, sentence, vc
     if args.tiny:
         vc = V.CLIPVisionConfigLite(hidden=128, layers=3, heads=2, intermediate=256, patch=14, image_size=56)
         qc = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=32768)
@@ -167,7 +188,7 @@ def run_inference(args):
         else:
             video_path = os.path.join(args.video_dir, anno["info"]["class_1"], anno["info"]["video_path"])
             assert os.path.exists(video_path), "{} not exist ".format(video_path)
-            cap = Cv2Capture(video_path)
+            cap = Cv2Capture(video_path, vc.image_size)
         total_frames, frame_rate = cap.n, cap.fps
         frame_line = [0] + time_line
         long_memory_tree, short_memory_buffer = None, None

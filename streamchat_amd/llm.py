@@ -215,6 +215,11 @@ def _decode_one(self, embeds):
 Qwen2Model._decode_one = _decode_one
 
 
+def _lib_pick_bytes(B):
+    from . import _lib
+    return int(_lib.load().sc_pick_token_workspace_bytes(B))
+
+
 class DecodeGraph:
     """Greedy batch-1 decode captured ONCE as a hipGraph and replayed per token (the 13 launches x layers of a decode step are
     launch-bound from Python: cdna guide "capture launch-bound inner loops in hipGraphs").  Everything that changes from token to
@@ -231,6 +236,23 @@ class DecodeGraph:
         self.cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         self.out = torch.zeros(max_new_tokens, dtype=torch.int64, device=dev)
         self.graph = None
+        # Everything the captured graph reads or writes through a raw pointer is OWNED here or checked before every replay: a
+        # private split-KV workspace and token-pick workspace (the shared grow-only scratch of ops._workspace may be reallocated by
+        # any later launch — a k-means merge needs ~100 MB of it), and the KV-cache pointers recorded at capture (`valid()`).
+        c = lm.cfg
+        self.ws_attn = torch.empty(max(ops.attention_workspace_bytes(1, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
+                                   dtype=torch.uint8, device=dev)
+        self.ws_pick = torch.empty(max(_lib_pick_bytes(1), 256), dtype=torch.uint8, device=dev)
+        self.nxt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._captured_ptrs = None
+
+    def _ptrs(self):
+        return tuple(c.data_ptr() for c in self.lm.cache) + (self.lm.cache[0].shape[0],)
+
+    def valid(self):
+        """False once the KV cache was reallocated after capture (reset_cache with a larger max_seq): the graph would replay into
+        freed memory — the owner must drop it and capture a new one."""
+        return self.graph is None or self._captured_ptrs == self._ptrs()
 
     def _body(self):
         lm, c = self.lm, self.lm.cfg
@@ -243,12 +265,12 @@ class DecodeGraph:
             ck = lm.cache[l]
             qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
             att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
-                                kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
+                                kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh, ws=self.ws_attn).view(1, dq)
             h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
             m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
         logits = ops.gemv(lm.lm_head, h, None, out_f32=True, rms_gamma=lm.norm, rms_eps=c.eps)
-        nxt = torch.argmax(logits).reshape(1)
+        nxt = ops.pick_token(logits, out=self.nxt, ws=self.ws_pick)          # HIP arg-max over the 152 064 logits (sampling.hip)
         self.out.index_copy_(0, self.cnt, nxt)
         self.tok.copy_(nxt)
         self.pos.add_(1); self.len.add_(1); self.cnt.add_(1)
@@ -270,11 +292,16 @@ class DecodeGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logits = self._body()
+        self._captured_ptrs = self._ptrs()
         for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
             t.copy_(v)
 
     def run(self, n_tokens: int):
         """n greedy tokens; returns them as a CPU list (one sync at the end) and advances lm.cache_len"""
+        if not self.valid():
+            raise RuntimeError("DecodeGraph: the KV cache was reallocated after capture; build a new DecodeGraph")
+        if n_tokens > self.out.numel() or self.lm.cache_len + n_tokens > self.lm.cache[0].shape[0]:
+            raise ValueError("DecodeGraph.run: more tokens than the output ring / KV cache can hold")
         if self.graph is None:
             self.capture()
         for _ in range(n_tokens):
@@ -299,6 +326,7 @@ class BatchDecoder:
         dev = lm.device
         self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self._ws_pick = torch.empty(max(_lib_pick_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
         first_logits = []
         saved = (lm.cache, lm.cache_len, lm.max_seq)
         try:
@@ -329,7 +357,8 @@ class BatchDecoder:
             # the G query heads of a KV group as G query ROWS of that KV head (addressing only; q batch stride = dq)
             G = c.heads // c.kv_heads
             att = ops.attention(q.as_strided((B, G, Dh), (dq, Dh, 1)), ck[:, :, :dkv], ck[:, :, dkv:], c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,
-                                causal=False, kv_len=kvlen, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(B, dq)
+                                causal=False, kv_len=kvlen, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh,
+                                ws=self._ws_attn).view(B, dq)
             h2 = ops.gemm(att, L["wo"], None, residual=h)
             m = ops.gemm(ops.rmsnorm(h2, L["ln2"], c.eps), L["wgu"], None, epilogue="swiglu")
             h = ops.gemm(m, L["wd"], None, residual=h2)
@@ -337,9 +366,12 @@ class BatchDecoder:
         return ops.gemm(ops.rmsnorm(h, lm.norm, c.eps), lm.lm_head, None, out_f32=True)
 
     def _pick(self, logits, do_sample, temperature, generator=None):
+        """next token per sequence on the device (sampling.hip): arg-max, or a temperature-softmax sample at uniform draws taken
+        from `generator` (the default CUDA generator inside a captured graph: graph-safe offsets)"""
         if do_sample and temperature > 0:
-            return torch.multinomial(torch.softmax(logits / temperature, dim=-1), 1, generator=generator).view(-1)
-        return torch.argmax(logits, dim=-1)
+            u = torch.rand(logits.shape[0], device=logits.device, generator=generator)
+            return ops.pick_token(logits, temperature, u, ws=self._ws_pick)
+        return ops.pick_token(logits, ws=self._ws_pick)
 
     def _graph_body(self, do_sample, temperature):
         logits = self.step(self.tok)
@@ -354,8 +386,12 @@ class BatchDecoder:
         graph draws from the default CUDA generator, so a user `generator` selects the eager path.  EOS is checked on the host
         every 16 steps (sequences that are done keep stepping; their extra tokens are dropped)."""
         B, dev = self.B, self.lm.device
+        eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else (set() if eos_token_id is None else {eos_token_id})   # HF allows a list
         longest = int(self.len.max().item()) + max_new_tokens
         self.nsplit = max(1, min(64, ((longest + 63) // 64) // 4))
+        c = self.lm.cfg
+        self._ws_attn = torch.empty(max(ops.attention_workspace_bytes(B, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
+                                    dtype=torch.uint8, device=dev)
         self._row0 = torch.arange(B, device=dev, dtype=torch.int64) * self.cap
         first = self._pick(self.logits, do_sample, temperature, generator)
         self.out = torch.zeros((max_new_tokens, B), dtype=torch.int64, device=dev)
@@ -387,16 +423,17 @@ class BatchDecoder:
                 self.tok.copy_(nxt)
                 self.cnt.add_(1)
             steps += 1
-            if eos_token_id is not None and (steps % 16 == 0 or steps == max_new_tokens):
+            if eos and (steps % 16 == 0 or steps == max_new_tokens):
                 col = self.out[:steps].cpu()
-                if all((col[:, b] == eos_token_id).any() for b in range(B)):
+                if all(any(int(v) in eos for v in col[:, b]) for b in range(B)):
                     break
         toks = self.out[:steps].cpu().t().tolist()
         res = []
         for b in range(B):
             t = toks[b]
-            if eos_token_id is not None and eos_token_id in t:
-                t = t[:t.index(eos_token_id) + 1]
+            cut = next((i for i, v in enumerate(t) if v in eos), None)
+            if cut is not None:
+                t = t[:cut + 1]
             res.append(t)
         return res
 
@@ -459,9 +496,12 @@ class LlavaQwenForCausalLM:
         _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
-        if not (do_sample and temperature > 0) and self.eos_token_id is None and max_new_tokens > 1 and kwargs.get("decode_graph", True):
-            first = int(torch.argmax(logits).item())
-            if self._dg is None or self._dg.out.numel() < max_new_tokens:
+        if top_p not in (None, 1.0):
+            raise NotImplementedError("top_p sampling is not built (the reference passes top_p=None, inference_streaming_longva_v2.py:72)")
+        eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])
+        if not (do_sample and temperature > 0) and not eos and max_new_tokens > 1 and kwargs.get("decode_graph", True):
+            first = int(ops.pick_token(logits).item())
+            if self._dg is None or self._dg.out.numel() < max_new_tokens or not self._dg.valid():
                 self._dg = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256))
             self._dg.start(first)
             rest = self._dg.run(max_new_tokens - 1)
@@ -469,12 +509,11 @@ class LlavaQwenForCausalLM:
         new = []
         for step in range(max_new_tokens):
             if do_sample and temperature > 0:
-                probs = torch.softmax(logits / temperature, dim=-1)
-                tok = int(torch.multinomial(probs, 1, generator=generator).item())
+                tok = int(ops.pick_token(logits, temperature, torch.rand(1, device=self.device, generator=generator)).item())
             else:
-                tok = int(torch.argmax(logits).item())
+                tok = int(ops.pick_token(logits).item())
             new.append(tok)
-            if self.eos_token_id is not None and tok == self.eos_token_id:
+            if tok in eos:
                 break
             if step + 1 < max_new_tokens:
                 logits = self.lm.forward(self.lm.embed_tokens(torch.tensor([tok], device=self.device)))

@@ -1,4 +1,6 @@
-"""Prompt tokenisation with the `<image>` sentinel (mirror of reference longva/mm_utils.py:341-360)."""
+"""Prompt tokenisation with the `<image>` sentinel (mirror of reference longva/mm_utils.py:341-360) and the host half of
+`process_images` (reference utiles.py:71-87 -> CLIPImageProcessor.preprocess): resize + centre crop of a decoded frame."""
+import numpy as np
 import torch
 
 IMAGE_TOKEN_INDEX = -200
@@ -26,3 +28,25 @@ def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX
             return torch.tensor(input_ids, dtype=torch.long)
         raise ValueError(f"Unsupported tensor type: {return_tensors}")
     return input_ids
+
+
+def resize_center_crop_u8(frame, size=336):
+    """uint8 [H, W, 3] RGB frame of any resolution -> uint8 [size, size, 3]: what `CLIPImageProcessor.preprocess` does BEFORE the
+    rescale / normalise step that `sc_preprocess_*` fuses into the patch gather (reference utiles.py:71-87, inference_streaming_
+    longva_v2.py:503-516): shortest edge -> `size` with PIL bicubic (the long edge becomes int(size * long / short)), then a centre
+    crop with top = (h - size) // 2, left = (w - size) // 2.  Runs on the host next to the video decode; frames that already are
+    size x size pass through untouched (both steps are identities, as for the synthetic 336 x 336 streams).
+    Pinned against the processor itself in tests/test_checkpoint_and_frames.py."""
+    frame = np.asarray(frame)
+    if frame.ndim != 3 or frame.shape[2] != 3 or frame.dtype != np.uint8:
+        raise ValueError(f"resize_center_crop_u8: expected a uint8 [H, W, 3] frame, got {frame.dtype} {frame.shape}")
+    h, w = frame.shape[:2]
+    if (h, w) == (size, size):
+        return frame
+    from PIL import Image
+    short, long = (h, w) if h <= w else (w, h)
+    new_short, new_long = size, int(size * long / short)
+    nh, nw = (new_short, new_long) if h <= w else (new_long, new_short)
+    img = np.asarray(Image.fromarray(frame).resize((nw, nh), resample=Image.BICUBIC))
+    top, left = (nh - size) // 2, (nw - size) // 2
+    return np.ascontiguousarray(img[top:top + size, left:left + size])

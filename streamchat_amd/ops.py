@@ -76,7 +76,8 @@ class _timed:
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only per-device scratch (caller-owned memory handed to the library; 256-byte aligned)."""
-    key = (torch.device(device).index or 0)
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -191,11 +192,18 @@ def preprocess_patchify_u8(frames: torch.Tensor, patch: int, ld: int, mean=CLIP_
     """uint8 [N, H, W, 3] -> fp16 patch rows [N*(H/p)*(W/p), ld] (normalised, im2col order c,py,px; zero padded)."""
     _require_cuda(frames)
     lib = _lib.load()
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise StreamChatHipError("preprocess_patchify_u8: frames must be uint8 [N, H, W, 3]")
     frames = frames.contiguous()
     n, h, w, _ = frames.shape
+    if h % patch or w % patch:
+        raise StreamChatHipError(f"preprocess_patchify_u8: {h}x{w} frames are not a multiple of the patch size {patch} "
+                                 "(resize + centre-crop to the tower's image_size first: mm_utils.resize_center_crop_u8)")
     rows = n * (h // patch) * (w // patch)
     if out is None:
         out = torch.empty((rows, ld), dtype=torch.float16, device=frames.device)
+    elif out.shape[0] < rows or out.shape[1] != ld or out.dtype != torch.float16 or not out.is_contiguous():
+        raise StreamChatHipError(f"preprocess_patchify_u8: out must be a contiguous fp16 [>= {rows}, {ld}] buffer, got {tuple(out.shape)}")
     with torch.cuda.device(frames.device):
         check(lib.sc_preprocess_patchify_u8(ptr(frames), n, h, w, patch, _f3(mean), _f3(std), ptr(out), ld, stream_ptr(frames.device)),
               "sc_preprocess_patchify_u8")
@@ -218,6 +226,36 @@ def sim_topk(q: torch.Tensor, docs: torch.Tensor, k: int = 1, metric: str = "cos
         check(lib.sc_sim_topk(ptr(q), ptr(docs), M, d, k, 0 if metric == "cos" else 1, ptr(idx), ptr(score), stream_ptr(docs.device)),
               "sc_sim_topk")
     return idx, score
+
+
+def pick_token(logits: torch.Tensor, temperature: float = 0.0, u=None, out=None, ws=None):
+    """Next token ids [B] int64 from fp32 logits [B, V] (or [V]): arg-max (temperature <= 0, lowest index on ties) or a sample from
+    softmax(logits / temperature) at the uniform draws `u` [B] (device fp32 in [0, 1)).  No host sync; graph-capturable when `ws`
+    (a private uint8 buffer of sc_pick_token_workspace_bytes(B)) is passed."""
+    _require_cuda(logits)
+    lib = _lib.load()
+    if logits.dtype != torch.float32:
+        raise StreamChatHipError("pick_token: fp32 logits expected")
+    lg = logits if logits.dim() == 2 else logits.view(1, -1)
+    if lg.stride(1) != 1:
+        raise StreamChatHipError("pick_token: logits rows must be contiguous")
+    B, V = lg.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=lg.device)
+    need = lib.sc_pick_token_workspace_bytes(B)
+    if ws is None:
+        ws = _workspace(need, lg.device)
+    if temperature > 0:
+        if u is None:
+            raise StreamChatHipError("pick_token: sampling needs the uniform draws u")
+        u = u.to(device=lg.device, dtype=torch.float32).contiguous().view(-1)
+        if u.numel() != B:
+            raise StreamChatHipError("pick_token: u must have one entry per row")
+    from ctypes import c_void_p
+    with torch.cuda.device(lg.device):
+        check(lib.sc_pick_token_f32(c_void_p(lg.data_ptr()), B, V, c_int64(lg.stride(0)), c_float(float(temperature)), ptr(u) if temperature > 0 else None,
+                                    ptr(out), ptr(ws), c_size_t(ws.numel()), stream_ptr(lg.device)), "sc_pick_token_f32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -280,8 +318,12 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
     return out
 
 
+def attention_workspace_bytes(B: int, Hq: int, Sq: int, nsplit: int, Dh: int) -> int:
+    return B * Hq * Sq * nsplit * (Dh + 2) * 4 if nsplit > 1 else 0
+
+
 def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1,
-              q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None):
+              q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None, ws=None):
     """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused
     QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh]."""
     _require_cuda(q, k, v)
@@ -297,10 +339,17 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
     ldo = out.stride(1) if out_ld is None else out_ld
     kl = None if kv_len is None else kv_len.to(device=q.device, dtype=torch.int32).contiguous()
-    ws = _workspace(B * Hq * Sq * nsplit * (Dh + 2) * 4, q.device) if nsplit > 1 else None
+    if nsplit > 1:              # split-KV partials: the shared grow-only scratch, or a caller-owned buffer (anything a hipGraph captures)
+        need = attention_workspace_bytes(B, Hq, Sq, nsplit, Dh)
+        if ws is None:
+            ws = _workspace(need, q.device)
+        elif ws.numel() * ws.element_size() < need:
+            raise StreamChatHipError(f"attention: workspace {ws.numel() * ws.element_size()} < required {need}")
+    else:
+        ws = None
     with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), ldo, B, Sq, Skv, Hq, Hkv, Dh,
-                                   c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel()),
+                                   c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel() * ws.element_size()),
                                    q_head_stride, o_head_stride, c_int64(q.stride(0) if B > 1 else 0), c_int64(out.stride(0) if B > 1 else 0),
                                    stream_ptr(q.device)), "sc_attention_f16")
     return out
@@ -327,9 +376,13 @@ def patchify_f16(pixel_values: torch.Tensor, patch: int, ld: int, out=None) -> t
     if x.dtype != torch.float16:
         raise StreamChatHipError("patchify_f16: fp16 pixel values expected")
     n, _, h, w = x.shape
+    if h % patch or w % patch:
+        raise StreamChatHipError(f"patchify_f16: {h}x{w} images are not a multiple of the patch size {patch}")
     rows = n * (h // patch) * (w // patch)
     if out is None:
         out = torch.empty((rows, ld), dtype=torch.float16, device=x.device)
+    elif out.shape[0] < rows or out.shape[1] != ld or out.dtype != torch.float16 or not out.is_contiguous():
+        raise StreamChatHipError(f"patchify_f16: out must be a contiguous fp16 [>= {rows}, {ld}] buffer, got {tuple(out.shape)}")
     with torch.cuda.device(x.device):
         check(lib.sc_patchify_f16(ptr(x), n, h, w, patch, ptr(out), ld, stream_ptr(x.device)), "sc_patchify_f16")
     return out

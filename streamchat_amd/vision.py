@@ -174,11 +174,16 @@ class FrameEncoder:
         """images: [N, 3, H, W] fp16 normalised pixel values (what the reference passes) -> [N, 576, 3584] fp16."""
         c = self.tower.cfg
         images = images.to(device=self.tower.device, dtype=torch.float16)
+        if tuple(images.shape[2:]) != (c.image_size, c.image_size):
+            raise ValueError(f"encode_images: pixel values are {tuple(images.shape[2:])}, the tower takes {c.image_size} x {c.image_size}")
         return self._run(images.shape[0], lambda s, n, buf: ops.patchify_f16(images[s:s + n], c.patch, self.tower.kpad,
                                                                             out=buf[: n * c.num_patches]), out)
 
     def encode_frames_u8(self, frames, out=None):
         """frames: uint8 [N, H, W, 3] RGB — preprocessing (reference utiles.py:71-87) fused into the patch gather."""
         c = self.tower.cfg
+        if tuple(frames.shape[1:3]) != (c.image_size, c.image_size):
+            raise ValueError(f"encode_frames_u8: frames are {tuple(frames.shape[1:3])}, the tower takes {c.image_size} x {c.image_size} "
+                             "(resize + centre-crop first: streamchat_amd.mm_utils.resize_center_crop_u8, the CLIPImageProcessor step of utiles.py:71-87)")
         return self._run(frames.shape[0], lambda s, n, buf: ops.preprocess_patchify_u8(frames[s:s + n], c.patch, self.tower.kpad,
                                                                                       out=buf[: n * c.num_patches]), out)

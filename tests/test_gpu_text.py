@@ -1,11 +1,13 @@
 """GPU: HIP text encoders vs the HF golden vectors (tiny BertModel) and the fp32 PyTorch restatement at
-all-MiniLM-L6 / BERT-large widths.  Tolerance: fp16 storage, fp32 accumulate -> 2e-2 of max magnitude; the
+all-MiniLM-L6 / BERT-large widths.  Tolerance: fp16 storage, fp32 accumulate -> tests/_tol.py (max 4e-3 of max magnitude, rms 3e-3, per-row cosine 0.9999); the
 retrieval INDICES derived from the embeddings must equal the fp32 ones exactly."""
 import os
 
 import numpy as np
 import pytest
 import torch
+
+from tests._tol import assert_close_fp16
 
 import oracle
 from oracle import torch_ref as R
@@ -24,7 +26,7 @@ def test_bert_tiny_vs_hf_golden():
     out = enc(input_ids=ids.cuda(), attention_mask=mask.cuda()).last_hidden_state
     ref = torch.from_numpy(d["last_hidden_state"]).cuda()
     m = mask.bool().cuda()
-    assert (out.float() - ref)[m].abs().max().item() < 2e-2 * ref[m].abs().max().item()
+    assert_close_fp16(out.float()[m], ref[m], what="tiny BERT last_hidden_state vs HF golden")
 
 
 @pytest.mark.parametrize("name,cfgd,layers", [("minilm", T.MINILM_L6, 6), ("bert-large", T.BERT_LARGE, 3)])
@@ -45,7 +47,7 @@ def test_sentence_and_cls_embeddings_vs_torch_fp32(name, cfgd, layers):
         emb = enc.embed_cls(ids, mask.sum(1))
         ref = R.bert_last_hidden(sdf, ids, mask, heads=cfg.heads, layers=layers)[:, 0]
     assert emb.dtype == torch.float32
-    assert (emb - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert_close_fp16(emb, ref, what=f"{name} embeddings vs fp32 torch_ref")
     # retrieval built on top: identical top-k indices from the fp16-pipeline embeddings and the fp32 ones
     q = ref[4] + 0.05 * ref[2]
     metric = "l2" if name == "minilm" else "cos"

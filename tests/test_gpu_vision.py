@@ -1,12 +1,14 @@
 """GPU: the HIP frame encoder (`encode_images`) against (a) the golden vectors produced by the real HF
 CLIPVisionModel (tools/make_golden_hf.py) and (b) the fp32 PyTorch restatement at ViT-L/14-336 size.
-Tolerance: fp16 storage of weights/activations with fp32 accumulation -> 2e-2 of the output's max magnitude
+Tolerance (tests/_tol.py): max|err| <= 4e-3 max|ref|, rms(err) <= 3e-3 rms(ref), per-row cosine >= 0.9999 (fp16 storage, fp32 accumulate)
 (observed ~3e-3); stated per test."""
 import os
 
 import numpy as np
 import pytest
 import torch
+
+from tests._tol import assert_close_fp16
 
 from oracle import torch_ref as R
 from streamchat_amd import ops, vision as V
@@ -29,8 +31,7 @@ def test_encode_images_tiny_vs_hf_golden():
     out = enc.encode_images(torch.from_numpy(d["pixel_values"]).cuda().half())
     ref = torch.from_numpy(d["projected"]).cuda()
     assert out.shape == ref.shape == (3, 16, 256)
-    err = (out.float() - ref).abs().max().item()
-    assert err < 2e-2 * ref.abs().max().item(), err
+    assert_close_fp16(out, ref, what="tiny CLIP + projector vs HF golden")
 
 
 def test_feature_select_layer_and_cls_patch():
@@ -42,7 +43,7 @@ def test_feature_select_layer_and_cls_patch():
     h = R.clip_vision_hidden(sd, px, heads=2, patch=14, layers_run=3)
     ref = R.mm_projector(sp, h).cuda()
     assert out.shape == (3, 17, 256)
-    assert (out.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert_close_fp16(out, ref, what="tiny CLIP select_layer=-1 cls_patch")
     with pytest.raises(ValueError):
         V.CLIPVisionTower(sd, cfg, select_feature="bogus")
 
@@ -67,8 +68,7 @@ def test_encode_images_vit_l_vs_torch_fp32():
     assert out.shape == (3, 576, 3584) and out.dtype == torch.float16
     px = ops.preprocess_u8(u8).float()
     ref = R.encode_images({k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in sp.items()}, px, heads=16, patch=14, num_layers=24)
-    err = (out.float() - ref).abs().max().item()
-    assert err < 2e-2 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert_close_fp16(out, ref, what="ViT-L/14-336 + mlp2x_gelu vs fp32 torch_ref")
     # frames are independent: encoding frame 1 alone gives the same rows as inside the batch
     single = enc.encode_frames_u8(u8[1:2])
     assert torch.equal(single[0], out[1])
