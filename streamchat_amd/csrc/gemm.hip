@@ -892,6 +892,11 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const _Float16* __restrict_
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
+    // hipFuncSetAttribute and the CU count are PER DEVICE: the flags below are indexed by the current device, so a process that drives
+    // several GPUs (the reference puts its two model replicas on cuda:0 / cuda:1) raises the LDS limit on each of them
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
     static int force = -1;                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
     if (force == 0 && M <= 32 && K % 128 == 0 && a_grp == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0)) {      // few rows: stream W once
@@ -918,18 +923,19 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         const size_t lds2 = half ? 3 * (128 * BK2 * 2 + HALF2) : SC_GEMM_NS * STAGE2;
         const void* fn = half ? (out_f32 ? (const void*)k_gemm256<EPI, true, 1> : (const void*)k_gemm256<EPI, false, 1>)
                               : (out_f32 ? (const void*)k_gemm256<EPI, true, 2> : (const void*)k_gemm256<EPI, false, 2>);
-        static bool attr_done[16] = {};
+        static bool attr_done[16][16] = {};
         const int ai = EPI * 4 + (out_f32 ? 2 : 0) + (half ? 1 : 0);
-        if (!attr_done[ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[ai] = true; }
+        if (!attr_done[dev][ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[dev][ai] = true; }
         // persistent walk (one workgroup per CU) when a workgroup gets more than one tile; needs an even number of K-steps (the
         // fragment register sets ping-pong in pairs) and at least DIST + 1 of them.  SC_GEMM_PERSIST=0 switches it off (A/B runs).
-        static int persist = -1, n_cu = 0;
-        if (persist < 0) {
-            const char* e = getenv("SC_GEMM_PERSIST"); persist = e ? atoi(e) : 1;
-            int dev = 0; hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
-            if (n_cu <= 0) n_cu = 256;
+        static int persist = -1, n_cu_dev[16] = {};
+        if (persist < 0) { const char* e = getenv("SC_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+        if (n_cu_dev[dev] == 0) {
+            int cur = 0, n = 0;
+            if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
+            if (n_cu_dev[dev] <= 0) n_cu_dev[dev] = 256;
         }
+        const int n_cu = n_cu_dev[dev];
         const int nt_all = tM * tN, nk2 = K / BK2;
         // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
         static int fat = -1;
@@ -940,10 +946,10 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
             // fetched under the epilogue of the current one
             const bool fp = persist && fat != 2 && nt_all > n_cu;
-            static bool fattr[8][2] = {};
-            if (!fattr[EPI][fp]) {
+            static bool fattr[16][8][2] = {};
+            if (!fattr[dev][EPI][fp]) {
                 (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
-                fattr[EPI][fp] = true;
+                fattr[dev][EPI][fp] = true;
             }
             if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                        (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
@@ -958,8 +964,8 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         hipLaunchKernelGGL((k_gemm256<EPI, F32, WRV>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
                            (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all)
         if (pers) {
-            static bool pattr[8] = {};
-            if (!pattr[EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm256<EPI, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); pattr[EPI] = true; }
+            static bool pattr[16][8] = {};
+            if (!pattr[dev][EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm256<EPI, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); pattr[dev][EPI] = true; }
             hipLaunchKernelGGL((k_gemm256<EPI, false, 2, true>), dim3((unsigned)n_cu), block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W,
                                (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all);
         }

@@ -29,15 +29,20 @@ class AsyncFrameIngest:
         self.ready = queue.Queue(maxsize=depth)
         self.stats = dict(frames=0, micro_batches=0, producer_waits=0)
         self._err = None
+        self._stop = False
 
     def _producer(self, frames):
         try:
             slot, n = None, 0
             for f in frames:
+                if self._stop:
+                    return
                 if slot is None:
                     if self.free.empty():
                         self.stats["producer_waits"] += 1
                     slot, n = self.free.get(), 0
+                    if slot is None or self._stop:          # the consumer failed and released us
+                        return
                 self.stage[slot][n].copy_(torch.as_tensor(np.ascontiguousarray(f)) if not torch.is_tensor(f) else f)
                 n += 1
                 if n == self.mb:
@@ -53,10 +58,43 @@ class AsyncFrameIngest:
     def run(self, frames, bank, start=0):
         """Encode every frame of the iterable `frames` into bank[start:...] in order.  Returns the number of frames written.  The
         call returns after the last encode has been ISSUED on the current stream (no synchronisation)."""
+        self._stop, self._err = False, None
         t = threading.Thread(target=self._producer, args=(frames,), daemon=True)
         t.start()
         pos = start
         copied = [None] * self.depth               # events: device buffer i was consumed by an encode -> its staging slot is free
+        try:
+            pos = self._consume(bank, pos, start, copied)
+        except BaseException:
+            # bank overflow / encode error mid-stream: stop the producer (it may be blocked on free.get()) before re-raising, so the
+            # thread and its staging slots are not leaked
+            self._stop = True
+            self.free.put(None)
+            while t.is_alive():
+                try:
+                    self.ready.get(timeout=0.05)
+                except Exception:
+                    pass
+            t.join()
+            self._reset_queues()
+            raise
+        t.join()
+        if self._err is not None:
+            raise self._err
+        return pos - start
+
+    def _reset_queues(self):
+        import queue
+        for q in (self.free, self.ready):
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+        for i in range(self.depth):
+            self.free.put(i)
+
+    def _consume(self, bank, pos, start, copied):
         while True:
             item = self.ready.get()
             if item is None:
@@ -85,7 +123,4 @@ class AsyncFrameIngest:
             pos += n
             self.stats["frames"] += n
             self.stats["micro_batches"] += 1
-        t.join()
-        if self._err is not None:
-            raise self._err
-        return pos - start
+        return pos

@@ -114,9 +114,12 @@ def weighted_kmeans_feature(img_feature, video_max_frames, weights=None, *, init
 
     Determinism: the reference draws its initial rows with `torch.randperm(device=...)` (:295) and its
     empty-cluster reseeds with `random.randint` (:313).  Both are explicit here: `init_idx` defaults to a
-    CPU `torch.randperm(T)[:K]` (global CPU generator) and `reseed_idx` to max_iter*K draws from a COPY of
-    Python's global `random` state (the global state is not advanced).  Arithmetic is fp32-canonical
-    (the reference's fp16 distances overflow to inf — SURVEY.md §0 item 4)."""
+    CPU `torch.randperm(T)[:K]` (global CPU generator) and `reseed_idx` to max_iter*K draws of `random.randint(0, T-1)`
+    from Python's GLOBAL `random` state, which IS advanced (by all max_iter*K draws — the reference advances it by one draw per
+    empty cluster actually met, which the device-side loop cannot report without a host round trip per iteration; successive
+    calls therefore see fresh reseed rows like upstream, but a caller that shares `random` with other code sees a different
+    stream position than upstream after a call).  Arithmetic is fp32-canonical (the reference's fp16 distances overflow to inf
+    — SURVEY.md §0 item 4)."""
     if weights is None:
         weights = torch.ones(img_feature.size(0), dtype=img_feature.dtype, device=img_feature.device)
     T, P, D = img_feature.shape
@@ -127,9 +130,7 @@ def weighted_kmeans_feature(img_feature, video_max_frames, weights=None, *, init
     if init_idx is None:
         init_idx = torch.randperm(T)[:T0]
     if reseed_idx is None:
-        r = random.Random()
-        r.setstate(random.getstate())
-        reseed_idx = [r.randint(0, T - 1) for _ in range(max_iter * T0)]
+        reseed_idx = [random.randint(0, T - 1) for _ in range(max_iter * T0)]
     C, labels, wsum, info = ops.kmeans_fit(X, T0, init_idx, reseed_idx, weights=weights, max_iter=max_iter, tol=tol)
     reduced_feature = C.view(T0, P, D).to(img_feature.dtype)
     if return_info:
@@ -138,10 +139,14 @@ def weighted_kmeans_feature(img_feature, video_max_frames, weights=None, *, init
 
 
 def k_means_clustering(X, num_clusters, max_iter=10, *, init_idx=None):
-    """utiles.py:332-345: plain (unweighted) Lloyd on [N, D] rows; returns (centroids, labels)."""
+    """utiles.py:332-345: plain (unweighted) Lloyd on [N, D] rows; returns (centroids, labels).  Upstream stops when
+    `torch.allclose(centroids, new_centroids)` (rtol 1e-5, atol 1e-8) and then keeps the OLD centroids; here the exit test is the
+    kernels' sum_k ||dC_k||_2 < 1e-6 (a fixed point of Lloyd's iteration moves nothing, so both stop at the same iteration on
+    converging data and the old / new centroids then agree to that tolerance).  An empty cluster's mean is NaN upstream (0/0); here
+    it is re-seeded with row 0 — documented divergence, upstream's NaN centroid can never be assigned a point again."""
     if init_idx is None:
         init_idx = torch.randperm(X.size(0))[:num_clusters]
-    C, labels, _, _ = ops.kmeans_fit(X, num_clusters, init_idx, None, max_iter=max_iter, tol=0.0)
+    C, labels, _, _ = ops.kmeans_fit(X, num_clusters, init_idx, None, max_iter=max_iter, tol=1e-6)
     return C.to(X.dtype), labels
 
 

@@ -33,3 +33,24 @@ def test_bank_overflow_and_producer_error_are_loud():
     ing2 = AsyncFrameIngest(_enc, (2, 2, 3), micro_batch=2, depth=2, device="cpu")
     with pytest.raises(RuntimeError, match="decoder died"):
         ing2.run(bad(), torch.zeros(4, 1, 3))
+
+
+def test_consumer_failure_stops_the_producer_and_the_pipeline_is_reusable():
+    """an exception in run() (bank overflow / encode error mid-stream) must not leave the producer thread blocked on
+    free.get() forever; afterwards the same ingest object works again."""
+    import threading
+    before = threading.active_count()
+    ing = AsyncFrameIngest(_enc, (2, 2, 3), micro_batch=2, depth=2, device="cpu")
+    with pytest.raises(ValueError):
+        ing.run(iter(np.zeros((50, 2, 2, 3), np.uint8)), torch.zeros(4, 1, 3))         # 50 frames into a 4-frame bank
+
+    def boom(frames, out):
+        raise RuntimeError("encode failed")
+    ing_b = AsyncFrameIngest(boom, (2, 2, 3), micro_batch=2, depth=2, device="cpu")
+    with pytest.raises(RuntimeError, match="encode failed"):
+        ing_b.run(iter(np.zeros((50, 2, 2, 3), np.uint8)), torch.zeros(64, 1, 3))
+    assert threading.active_count() == before                                          # both producers are gone
+    frames = np.arange(6 * 12, dtype=np.uint8).reshape(6, 2, 2, 3)
+    bank = torch.zeros(6, 1, 3)
+    assert ing.run(iter(frames), bank) == 6
+    assert torch.equal(bank[:, 0], torch.from_numpy(frames).float().mean(dim=(1, 2)))
