@@ -11,7 +11,9 @@ A "step" is one pass of the hot path over one synthetic 336x336 frame stream:
   answer   [short | retrieved] frame tokens + prompt -> Qwen2-7B prefill + first token                      [MFMA]
 Workloads (BASELINE.json configs):  C3 (default, the configuration the metric is quoted on): 1024 frames per GPU, full path;
 C2 = C3 without the LLM; C1 = 64 frames, encode + k-means(k=8); C4 = ONE 4096-frame stream sharded over the N ranks
-(strong scaling), all-gather of the selected features, 7B prefill on rank 0.  With N > 1 the stream is ONE global stream dealt to
+(strong scaling), all-gather of the selected features, 7B prefill on rank 0; C5 = ONE 8192-frame ego stream in 8 question rounds of
+1024 new frames: every round shards its segment over the ranks, grows the ONE persistent memory tree (short / long memory),
+retrieves (BERT-large CLS tree search + MiniLM dialogue memory), prefills and decodes 64 tokens on rank 0 (a "step" = the session).  With N > 1 the stream is ONE global stream dealt to
 the ranks by whole chunks and the memory update has single-stream semantics (streamchat_amd/sharded.py): the retrieved frames do
 not depend on N.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0)."""
 import argparse
@@ -44,7 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4"], default=None)
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4", "C5"], default=None)
+    ap.add_argument("--rounds", type=int, default=8, help="C5: question rounds per session (1024 new frames each)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU (C2/C3) or in total (C1/C4); default: the config's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llm", action="store_true", help="C2 workload: stop after retrieval (no 7B prefill)")
@@ -57,7 +60,7 @@ def parse():
 class Pipeline:
     """`n_total` frames of ONE global stream; this rank holds (and encodes) the frames `parts[rank]` of it."""
 
-    def __init__(self, device, n_total, seed=1234, with_llm=True, ctx=None, micro_batch=MICRO_BATCH, kmeans_k=None):
+    def __init__(self, device, n_total, seed=1234, with_llm=True, ctx=None, micro_batch=MICRO_BATCH, kmeans_k=None, max_seq=53248):
         self.ctx = ctx or DD.DistContext(0, 1, device)
         cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
         self.cfg = cfg
@@ -86,7 +89,7 @@ class Pipeline:
         if with_llm:        # LongVA-7B language side: Qwen2-7B shape, random-init fp16 (15 GB), KV cache for 52k tokens
             qc = LM.Qwen2ConfigLite(**LM.QWEN2_7B)
             sd = LM.random_qwen2_state_dict(qc, seed=4, device=device)
-            self.model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, qc, device=device, max_seq=53248, consume=True), self.enc)
+            self.model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, qc, device=device, max_seq=max_seq, consume=True), self.enc)
             del sd
             torch.cuda.empty_cache()
         self.llm_tok = synthetic.SyntheticTokenizer()
@@ -173,6 +176,60 @@ class Pipeline:
             self.last["image_embeddings"] = image_embeddings = sel.reshape(-1, sel.shape[-1])
             if self.model is not None:
                 self.prefill(image_embeddings, path_text[-1])
+        return self.last
+
+    # ---- C5: multi-round session over ONE growing stream ----
+    def prepare_rounds(self, rounds, per_round, seed=1234):
+        """round r = frames [r*per_round, (r+1)*per_round) of the global stream, dealt to the ranks by whole chunks; every round keeps
+        its own feature bank (tree nodes of earlier rounds keep referring to it, as the reference's node tensors do, utiles.py:561)."""
+        self.round_parts = DD.partition_chunks(per_round, MEM["chunk_size"], self.ctx.world)
+        a, b = self.round_parts[self.ctx.rank]
+        self.per_round = per_round
+        self.round_frames = [torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=r * per_round + a)).to(self.device) for r in range(rounds)]
+        self.round_feats = [torch.empty((b - a, self.cfg.num_patches, 3584), dtype=torch.float16, device=self.device) for _ in range(rounds)]
+        self.questions = [f"round {r}: where did I leave the {synthetic.VOCAB[(7 * r) % len(synthetic.VOCAB)]} and what was next to the "
+                          f"{synthetic.VOCAB[(11 * r + 3) % len(synthetic.VOCAB)]}" for r in range(rounds)]
+
+    def session(self, decode_tokens=64):
+        ctx = self.ctx
+        cap, tok = synthetic.SyntheticCaptioner(self.device), synthetic.SyntheticTokenizer()
+        torch.manual_seed(0)
+        rng = np.random.RandomState(0)
+        mem = SH.ShardedMemory(ctx, **MEM)
+        cache = U.CaptionEmbeddingCache()                    # caption embeddings persist across the rounds of a session (SURVEY 8(f).2)
+        log = []
+        for r, (frames, feats) in enumerate(zip(self.round_frames, self.round_feats)):
+            self._tag("encode")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if frames.shape[0]:
+                self.enc.encode_frames_u8(frames, out=feats)
+            e1.record()
+            self.enc_events.append((e0, e1))
+            self._tag("select")
+            tree, short = mem.update(feats, self.per_round, cap, tok, rng=rng)
+            self._tag("retrieve")
+            self.question = self.questions[r]
+            wanted, path_text = None, None
+            if ctx.is_root:
+                self.dialogue_search()
+                path, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, feats, self.colbert, self.tok, cache=cache)
+                wanted = list(short) + list(path)
+            wanted = mem.broadcast_refs(wanted)
+            sel = mem.fetch(wanted, dst=0, mode="allgather")
+            rec = dict(wanted=[mem.frames_of(x) for x in wanted], path_text=path_text, top=[(n.depth, n.centroids.rows) for n in tree])
+            if ctx.is_root and self.model is not None:
+                self.prefill(sel.reshape(-1, sel.shape[-1]), path_text[-1])
+                rec["context"] = self.last["context"]
+                if decode_tokens > 0:
+                    self._tag("decode")
+                    lm = self.model.lm
+                    if getattr(self, "_dg", None) is None or not self._dg.valid():
+                        self._dg = LM.DecodeGraph(lm, max_new_tokens=max(decode_tokens, 16))
+                    self._dg.start(int(self.last["first_token"][0, 0]))
+                    rec["tokens"] = self._dg.run(decode_tokens)
+            log.append(rec)
+        self.last.update(rounds=log, mem=mem, tree=mem.tree)
         return self.last
 
     def decode_rate(self, n_tokens):
@@ -271,9 +328,11 @@ def main():
     torch.cuda.set_device(dev)
     ctx = DD.DistContext(rank, world, dev, "nccl")
     config = a.config or ("C2" if a.no_llm else "C3")
-    full = config in ("C3", "C4")
+    full = config in ("C3", "C4", "C5") and not a.no_llm
     if config == "C1":
         n_total, scaling = a.frames or 64, "strong"
+    elif config == "C5":
+        n_total, scaling = (a.frames or FRAMES) * a.rounds, "strong"   # ONE ego stream: `rounds` segments of 1024 frames over the N ranks
     elif config == "C4":
         n_total, scaling = a.frames or 4096, "strong"          # ONE 4096-frame stream over the N ranks
     else:
@@ -281,8 +340,14 @@ def main():
     sharded = world > 1 or a.force_sharded
     if config == "C1" and sharded:
         sys.exit("C1 (64 frames, one k-means over all of them) is a single-GPU configuration")
-    pipe = Pipeline(dev, n_total, with_llm=full and rank == 0, ctx=ctx, kmeans_k=8 if config == "C1" else None)
-    run_step = pipe.step_sharded if sharded else pipe.step
+    if config == "C5":
+        # every top-level merged node adds one retrieved chunk (23 040 tokens) to the context (utiles.py:715-748): ~210 k tokens by round 8
+        pipe = Pipeline(dev, 0, with_llm=full and rank == 0, ctx=ctx, max_seq=(a.rounds + 2) * 23040 + 8192)
+        pipe.prepare_rounds(a.rounds, n_total // a.rounds)
+        run_step = pipe.session
+    else:
+        pipe = Pipeline(dev, n_total, with_llm=full and rank == 0, ctx=ctx, kmeans_k=8 if config == "C1" else None)
+        run_step = pipe.step_sharded if sharded else pipe.step
 
     def barrier():
         if world > 1:
@@ -357,8 +422,11 @@ def main():
                  C3="C3: 1024-frame 336x336 stream per GPU, ViT-L/14-336(23 layers)+mlp2x_gelu encode, memory update (chunk 40, K 5, interval 10: one "
                     "k-means T=400), MiniLM flat-L2 + BERT-large-CLS tree retrieval, LongVA-7B (Qwen2-7B shape) prefill of the retrieved context + first token",
                  C4="C4: ONE 4096-frame stream sharded over the ranks by whole chunks, encode + chunk captions rank-local, single-stream tree policy "
-                    "(one k-means T=400), all-gather of the selected features, LongVA-7B prefill on rank 0")
-    out = dict(metric="frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
+                    "(one k-means T=400), all-gather of the selected features, LongVA-7B prefill on rank 0",
+                 C5=f"C5: ONE {n_total}-frame ego stream in {a.rounds} rounds of {n_total // a.rounds} frames: per round sharded encode, persistent short/long "
+                    "memory tree (one merge k-means per round), BERT-large-CLS tree search + MiniLM dialogue memory, LongVA-7B prefill + 64-token decode on rank 0")
+    out = dict(metric=f"frames/sec over a multi-round session (per round: encode+select+retrieve{'+7B prefill+64-token decode' if full else ''}), {n_total}-frame ego stream"
+               if config == "C5" else "frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
                "frames/sec end-to-end (encode+select" + ("" if config == "C1" else "+retrieve") + f"), {n_total // (world if scaling == 'weak' else 1)}-frame stream",
                value=round(value, 2), unit="frames/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling=scaling,
@@ -367,7 +435,10 @@ def main():
                            micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""), weights="random-init"),
                encode_frames_per_s=round(enc_fps, 1), encode_ms_per_step=round(t_enc / a.steps * 1e3, 2),
                roofline=roof, roofline_stages=stages, stages=per)
-    if full and a.decode_tokens > 0 and world == 1:
+    if config == "C5":
+        out["config"]["rounds"] = [dict(context=r.get("context"), top_level_nodes=len(r["top"]), frames_retrieved=sum(len(x) for x in r["wanted"]))
+                                   for r in pipe.last["rounds"]]
+    if full and a.decode_tokens > 0 and world == 1 and config != "C5":
         rate = pipe.decode_rate(a.decode_tokens)         # greedy, batch 1, after the timed region (512 tokens)
         ctxlen = pipe.last["context"] + a.decode_tokens / 2
         gb_tok = 14.1 + 2 * 28 * 4 * 128 * ctxlen * 2 / 1e9       # fp16 weights incl. lm_head + KV bytes per token

@@ -60,6 +60,8 @@ class KernelTimer:
 class _timed:
     def __init__(self, name, work):
         self.kt = KernelTimer.active
+        if self.kt is not None and torch.cuda.is_current_stream_capturing():
+            self.kt = None                      # events recorded inside a hipGraph capture cannot be timed
         if self.kt is not None:
             self.name, self.work = (f"{self.kt.tag}/{name}" if self.kt.tag else name), work
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

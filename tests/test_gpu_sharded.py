@@ -48,3 +48,34 @@ def test_encode_is_independent_of_how_the_stream_is_batched():
     for lo, hi in ((0, 40), (40, 47), (47, 119), (119, 120)):                   # a rank owning frames [lo, hi) encodes them on their own
         part = pipe.enc.encode_frames_u8(pipe.frames[lo:hi])
         assert torch.equal(part, whole[lo:hi])
+
+
+def test_c5_multi_round_session_equals_single_stream_functions():
+    """C5's control flow (bench.Pipeline.session: a persistent tree grown over several question rounds) at world size 1 vs the
+    reference-seam functions called round by round on the same frames: same tree, same retrieved frames, same feature rows."""
+    import numpy as np
+    import bench
+    from streamchat_amd import streaming as S, synthetic, utiles as U
+    dev = torch.device("cuda:0")
+    pipe = bench.Pipeline(dev, 0, with_llm=False)
+    pipe.prepare_rounds(3, 440)                                     # 11 chunks per round: a depth-0 merge in every round
+    got = pipe.session(decode_tokens=0)
+    # ---- the single-stream functions, round by round ----
+    cap, tok = synthetic.SyntheticCaptioner(dev), synthetic.SyntheticTokenizer()
+    torch.manual_seed(0)
+    rng = np.random.RandomState(0)
+    tree, cache = None, U.CaptionEmbeddingCache()
+    for r in range(3):
+        feats = pipe.round_feats[r]                                 # (encode is bit-reproducible: the session left the same rows here)
+        bank = [feats[i:i + 1] for i in range(feats.shape[0])]
+        tree, short = S.updating_memory_buffer(bank, tree, cap, tok, True, rng=rng, **bench.MEM)
+        path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, pipe.questions[r], feats, pipe.colbert, pipe.tok, cache=cache)
+        rec = got["rounds"][r]
+        assert rec["path_text"] == texts
+        assert rec["top"] == [(n.depth, int(n.centroids.shape[0])) for n in tree]
+        assert sum(len(x) for x in rec["wanted"]) == sum(int(t.shape[0]) for t in list(short) + list(path))
+    # final tree: identical structure and bit-identical merge centroids
+    assert _describe(got["tree"]) == _describe(tree)
+    mine = [got["mem"].fetch([n.centroids]) for n in got["tree"] if n.depth > 0]
+    ref = [n.centroids for n in tree if n.depth > 0]
+    assert len(mine) == 3 and all(torch.equal(a, b) for a, b in zip(mine, ref))
