@@ -202,6 +202,15 @@ int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void*
                      const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
                      int o_head_stride, int64_t q_batch_stride, int64_t o_batch_stride, sc_stream_t stream);
 
+/* Fused decode-step projection block: [q | k | v] = W . rmsnorm(x) + b, rotate-half RoPE (HF fp16 numerics) of q and k at position
+ * pos[0] (device int32), q -> q_out [q_heads*Dh], k | v -> cache row pos[0] (row stride cache_ld, K at column 0, V at kv_heads*Dh).
+ * One launch for the three small launches of a decode layer (q GEMV, kv GEMV, RoPE: HF Qwen2Attention q_proj / k_proj / v_proj +
+ * apply_rotary_pos_emb behind reference llava_qwen.py:155); bit-identical to sc_gemv_f16 x2 + sc_rope_qk_row_f16.
+ *   Wq [q_heads*Dh, K], Wkv [2*kv_heads*Dh, K] (k rows then v rows), bq / bkv biases or NULL, rms_gamma [K] or NULL (no norm). */
+int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma,
+                      float rms_eps, void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads,
+                      int Dh, int K, float theta, sc_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Next-token selection over fp32 LM-head logits.  Replaces what HF `generate` does after the forward pass
  * (reference llava_qwen.py:155 -> transformers GenerationMixin: argmax when do_sample=False; temperature softmax +

@@ -33,6 +33,8 @@ SIGNATURES = {
                             c_int, c_int, c_int, c_void_p]),
     "sc_vit_embed_ln_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_gemv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p]),
+    "sc_decode_qkv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                   c_int, c_int, c_float, c_void_p]),
     "sc_layernorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_rmsnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -9,7 +9,7 @@
 namespace {
 
 
-template <bool SWIGLU, bool OUT_F32, int RPW>
+template <bool SWIGLU, bool OUT_F32, int RPW, int UNR = 4>
 __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
                                               const _Float16* __restrict__ res, void* __restrict__ y_base, int N, int K,
                                               const int* __restrict__ y_row, int y_ld, const _Float16* __restrict__ gamma, float eps) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
     const _Float16* wp[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
-#pragma unroll 4
+#pragma unroll UNR
     for (int k = lane * 8; k < K; k += 512) {                       // (unrolled: >= 4 weight loads in flight per lane at RPW = 1)
         sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
         if (gamma) {
@@ -83,7 +83,93 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
     }
 }
 
+// Fused decode-step projection block (one launch instead of three: q GEMV, kv GEMV, RoPE — each of the small ones is a few us of
+// pure launch + latency inside the captured decode graph):
+//   [q | k | v] = W . rmsnorm(x) + b;  rotate-half RoPE of q and k at position p = pos[0];  q -> q_out,  k | v -> cache row p.
+// One wave owns the two rows (h, j) and (h, j + Dh/2) of a head, i.e. one RoPE rotation pair, so the rotation happens in the
+// epilogue of lane 0 with the arithmetic of k_rope_qk_row (llm_ops.hip: fp32 trig, cos / sin and every product rounded to fp16 like
+// HF's apply_rotary_pos_emb) on the fp16-rounded projections: bit-identical to the three-launch path.  V rows ride along unrotated.
+__global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__ Wq, const _Float16* __restrict__ Wkv, const _Float16* __restrict__ bq,
+                                                    const _Float16* __restrict__ bkv, const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
+                                                    float eps, _Float16* __restrict__ q_out, _Float16* __restrict__ cache, int ld,
+                                                    const int* __restrict__ pos, int Hq, int Hkv, int Dh, int K, float log2_theta) {
+    const int lane = threadIdx.x & 63;
+    const int half = Dh >> 1;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);                 // (head, j) over q heads, then k heads, then v heads
+    const int ntask = (Hq + 2 * Hkv) * half;
+    if (task >= ntask) return;
+    const int hh = task / half, j = task - hh * half;
+    const _Float16 *w0, *b0;
+    int kind, h;                                                          // 0 = q, 1 = k, 2 = v
+    if (hh < Hq) { kind = 0; h = hh; w0 = Wq + (size_t)(h * Dh + j) * (size_t)K; b0 = bq ? bq + h * Dh + j : nullptr; }
+    else if (hh < Hq + Hkv) { kind = 1; h = hh - Hq; w0 = Wkv + (size_t)(h * Dh + j) * (size_t)K; b0 = bkv ? bkv + h * Dh + j : nullptr; }
+    else { kind = 2; h = hh - Hq - Hkv; w0 = Wkv + (size_t)((Hkv + h) * Dh + j) * (size_t)K; b0 = bkv ? bkv + (Hkv + h) * Dh + j : nullptr; }
+    const _Float16* w1 = w0 + (size_t)half * (size_t)K;
+    float rstd = 1.f;
+    if (gamma) {
+        float ss = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        rstd = rsqrtf(ss / (float)K + eps);
+    }
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+    for (int k = lane * 8; k < K; k += 512) {
+        sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+        if (gamma) {
+            const sc_h8 gv = *reinterpret_cast<const sc_h8*>(gamma + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = (_Float16)((float)gv[e] * (float)(_Float16)((float)xv[e] * rstd));
+        }
+        const sc_h8 wa = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w0 + k));
+        const sc_h8 wb = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w1 + k));
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const sc_h2 b = {xv[e], xv[e + 1]};
+            acc0 = __builtin_amdgcn_fdot2(sc_h2{wa[e], wa[e + 1]}, b, acc0, false);
+            acc1 = __builtin_amdgcn_fdot2(sc_h2{wb[e], wb[e + 1]}, b, acc1, false);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { acc0 += __shfl_xor(acc0, m, 64); acc1 += __shfl_xor(acc1, m, 64); }
+    if (lane == 0) {
+        const int row = pos[0];
+        const _Float16 a = (_Float16)(acc0 + (b0 ? (float)b0[0] : 0.f)), b = (_Float16)(acc1 + (b0 ? (float)b0[half] : 0.f));
+        _Float16* dst = kind == 0 ? q_out + h * Dh + j : cache + (size_t)row * (size_t)ld + (kind == 1 ? 0 : Hkv * Dh) + h * Dh + j;
+        if (kind == 2) { dst[0] = a; dst[half] = b; return; }
+        const float inv_freq = exp2f(-log2_theta * (float)(2 * j) / (float)Dh);
+        float sn, cs;
+        sincosf((float)row * inv_freq, &sn, &cs);
+        const _Float16 c16 = (_Float16)cs, s16 = (_Float16)sn;
+        const _Float16 t1 = (_Float16)((float)a * (float)c16), t2 = (_Float16)((float)b * (float)s16);
+        const _Float16 t3 = (_Float16)((float)b * (float)c16), t4 = (_Float16)((float)a * (float)s16);
+        dst[0] = (_Float16)((float)t1 - (float)t2);
+        dst[half] = (_Float16)((float)t3 + (float)t4);
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma, float rms_eps,
+                                 void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh, int K, float theta,
+                                 sc_stream_t stream) {
+    SC_REQUIRE(Wq && Wkv && x && q_out && cache && pos, "sc_decode_qkv_f16: null pointer argument");
+    SC_REQUIRE(q_heads > 0 && kv_heads > 0 && Dh > 0 && Dh % 2 == 0 && K > 0 && K % 8 == 0, "sc_decode_qkv_f16: bad sizes");
+    SC_REQUIRE(cache_ld >= 2 * kv_heads * Dh, "sc_decode_qkv_f16: cache row stride too small for K | V");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
+               "sc_decode_qkv_f16: weights, x and gamma must be 16-byte aligned");
+    const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
+    hipLaunchKernelGGL(k_decode_qkv, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+                       (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
+                       cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta));
+    SC_CHECK_LAUNCH("sc_decode_qkv_f16");
+    return SC_OK;
+}
 
 extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const void* residual, void* y, int N, int K, int epilogue,
                            int out_f32, const int32_t* y_row, int y_ld, const void* rms_gamma, float rms_eps, sc_stream_t stream) {
@@ -98,8 +184,18 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     // rows per wave: 4 amortises the x loads when there are plenty of rows; 1 keeps >= ~900 workgroups in flight for the
     // 3584-row projections (224 workgroups at 4 rows/wave left most CUs with a single latency-bound workgroup)
     const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
-    const int rpw = few ? 1 : 4;
+    static int rpw_few = -1;                        // SC_GEMV_RPW_FEW=1|2|4: rows per wave of the small projections (A/B runs)
+    if (rpw_few < 0) { const char* e = getenv("SC_GEMV_RPW_FEW"); rpw_few = e ? atoi(e) : 1; }
+    const int rpw = few ? rpw_few : 4;
     const dim3 grid((unsigned)((N + 4 * rpw - 1) / (4 * rpw))), block(256);
+    if (few && !out_f32 && (rpw == 2 || rpw == 4 || (rpw_few == 1 && K >= 8192))) {
+        // long rows (the down projection, K = 18 944): two rows per wave and 8 x 16 B per lane in flight per row stream the 136 MB at
+        // 5.56 TB/s against 5.11 (profiles/r02_run18: A/B of rows-per-wave x unroll on a >1 GB weight cycle); short rows: 1 row, unroll 4
+        if (rpw == 4) hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+        else hipLaunchKernelGGL((k_gemv<false, false, 2, 8>), dim3((unsigned)((N + 7) / 8)), block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+        SC_CHECK_LAUNCH("sc_gemv_f16");
+        return SC_OK;
+    }
     if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
     else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
                         else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }

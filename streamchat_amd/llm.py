@@ -244,6 +244,7 @@ class DecodeGraph:
                                    dtype=torch.uint8, device=dev)
         self.ws_pick = torch.empty(max(_lib_pick_bytes(1), 256), dtype=torch.uint8, device=dev)
         self.nxt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.q_buf = torch.empty(c.heads * c.head_dim, dtype=torch.float16, device=dev)
         self._captured_ptrs = None
 
     def _ptrs(self):
@@ -259,9 +260,9 @@ class DecodeGraph:
         dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
         h = ops.gather_rows(self.tok, lm.embed)
         for l, L in enumerate(lm.L):
-            q = ops.gemv(L["wq"], h, L["bq"], rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)
-            ops.gemv(L["wkv"], h, L["bkv"], out=lm.cache[l], out_row=self.pos, rms_gamma=L["ln1"], rms_eps=c.eps)   # KV row `pos` of the cache
-            ops.rope_qk_row_(q, c.heads, lm.cache[l], self.pos, c.kv_heads, Dh, c.rope_theta)        # q and the new K row, one launch
+            # q / k / v projections + RMSNorm + RoPE + KV-cache append at row `pos`: one launch (gemv.hip k_decode_qkv)
+            q = ops.decode_qkv(L["wq"], L["wkv"], L["bq"], L["bkv"], h, L["ln1"], c.eps, self.q_buf, lm.cache[l], self.pos, c.heads, c.kv_heads, Dh,
+                               c.rope_theta).view(1, dq)
             ck = lm.cache[l]
             qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
             att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,

@@ -484,6 +484,19 @@ def gemv(w, x, bias=None, residual=None, epilogue: str = "none", out=None, out_f
     return out
 
 
+def decode_qkv(wq, wkv, bq, bkv, x, rms_gamma, rms_eps: float, q_out, cache, row_index, q_heads: int, kv_heads: int, Dh: int, theta: float):
+    """one launch: q / k / v projections of ONE token (fused RMSNorm), RoPE of q and k at position row_index[0] (device int32),
+    q -> q_out [q_heads*Dh], k | v -> cache[row_index[0]].  Bit-identical to gemv + gemv + rope_qk_row_."""
+    _require_cuda(wq, wkv, x, q_out, cache, row_index)
+    lib = _lib.load()
+    from ctypes import c_void_p
+    with torch.cuda.device(x.device), _timed("k_gemv", 2.0 * (wq.shape[0] + wkv.shape[0]) * wq.shape[1]):
+        check(lib.sc_decode_qkv_f16(ptr(wq), ptr(wkv), ptr(bq), ptr(bkv), ptr(x.reshape(-1)), ptr(rms_gamma), c_float(rms_eps), c_void_p(q_out.data_ptr()),
+                                    c_void_p(cache.data_ptr()), cache.stride(0), ptr(row_index), q_heads, kv_heads, Dh, wq.shape[1], c_float(theta),
+                                    stream_ptr(x.device)), "sc_decode_qkv_f16")
+    return q_out
+
+
 def rope_qk_row_(q, q_heads: int, cache, row_index, kv_heads: int, Dh: int, theta: float):
     """decode step: in-place RoPE of the query row `q` [q_heads*Dh] and of the K part of cache row `row_index` (device int32) - one launch."""
     _require_cuda(q, cache, row_index)

@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from streamchat_amd import ops
 S = int(sys.argv[1]); Hq, Hkv, Dh, causal = 28, 4, 128, True
-if len(sys.argv) > 2 and sys.argv[2] == "vit":
-    B, S, Hq, Hkv, Dh, causal = 56, 577, 16, 16, 64, False
+if len(sys.argv) > 2 and sys.argv[2].startswith("vit"):
+    B, S, Hq, Hkv, Dh, causal = (512 if sys.argv[2] == "vit512" else 56), 577, 16, 16, 64, False
 else:
     B = 1
 q = torch.randn(B, S, Hq * Dh, device="cuda").half(); k = torch.randn(B, S, Hkv * Dh, device="cuda").half(); v = torch.randn(B, S, Hkv * Dh, device="cuda").half()
