@@ -38,7 +38,7 @@ MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_PROFILE = "profiles/r01_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 
 
 def parse():
@@ -426,7 +426,8 @@ def main():
                  C5=f"C5: ONE {n_total}-frame ego stream in {a.rounds} rounds of {n_total // a.rounds} frames: per round sharded encode, persistent short/long "
                     "memory tree (one merge k-means per round), BERT-large-CLS tree search + MiniLM dialogue memory, LongVA-7B prefill + 64-token decode on rank 0")
     out = dict(metric=f"frames/sec over a multi-round session (per round: encode+select+retrieve{'+7B prefill+64-token decode' if full else ''}), {n_total}-frame ego stream"
-               if config == "C5" else "frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
+               if config == "C5" else f"frames/sec end-to-end (encode+select+retrieve+7B prefill), {n_total}-frame stream sharded over the ranks" if config == "C4" and full
+               else "frames/sec end-to-end (encode+select+retrieve+7B prefill), 1024-frame stream" if full else
                "frames/sec end-to-end (encode+select" + ("" if config == "C1" else "+retrieve") + f"), {n_total // (world if scaling == 'weak' else 1)}-frame stream",
                value=round(value, 2), unit="frames/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling=scaling,

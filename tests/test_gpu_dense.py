@@ -268,3 +268,39 @@ def test_gemm_full_size_llm_rows_vs_torch():
             z = (torch.nn.functional.silu(q4[:, :, 0]) * q4[:, :, 1]).reshape(rows.numel(), N // 2)
         torch.testing.assert_close(out[rows].float(), z, rtol=2e-3, atol=2e-3)
         del a, w, out
+
+
+def test_gemm_randomised_shape_stress():
+    """k_gemm_fat relies on hand-placed hazard guards that hipcc cannot see; a toolchain regression would show
+    up as rare wrong tiles.  60 seeded random (M, N, K, epilogue, bias, residual) combinations across all four kernels' dispatch
+    regions (ragged M, K % 128 != 0 fallbacks, many tiles per workgroup, single tiles), each against fp32 torch, twice in a row
+    (the second launch runs with warm caches and a different tile-to-CU timing)."""
+    import random
+    rnd = random.Random(20260928)
+    epis = ["none", "quick_gelu", "gelu", "swiglu"]
+    for case in range(60):
+        K = rnd.choice([64, 128, 192, 256, 384, 512, 1024, 1536, 3584, 4096])
+        N = rnd.choice([128, 256, 384, 512, 1024, 1280, 3072, 3584, 4096])
+        M = rnd.choice([1, 7, 33, 200, 577, 1023, 1024, 1025, 2500, 4099, 9000, 20000, 70000])
+        if M * N > 120e6 or M * K > 160e6:
+            M = 4099
+        epi = rnd.choice(epis)
+        use_bias, use_res = rnd.random() < 0.7, (rnd.random() < 0.5 and epi != "swiglu")
+        a, w = _rand((M, K), 1000 + case), _rand((N, K), 2000 + case, K ** -0.5)
+        b = _rand((N,), 3000 + case) if use_bias else None
+        z = a.float() @ w.float().t() + (b.float() if use_bias else 0)
+        if epi == "swiglu":
+            q = z.view(M, N // 4, 2, 2)
+            ref = (torch.nn.functional.silu(q[:, :, 0]) * q[:, :, 1]).reshape(M, N // 2)
+            r = None
+        else:
+            ref = z * torch.sigmoid(1.702 * z) if epi == "quick_gelu" else (torch.nn.functional.gelu(z) if epi == "gelu" else z)
+            r = _rand((M, N), 4000 + case) if use_res else None
+            if use_res:
+                ref = ref + r.float()
+        for rep in range(2):
+            out = ops.gemm(a, w, b, r, epi)
+            err = (out.float() - ref).abs()
+            tol = 2e-3 + 2e-3 * ref.abs()
+            bad = int((err > tol).sum())
+            assert bad == 0, (case, rep, M, N, K, epi, use_bias, use_res, bad, float(err.max()))
