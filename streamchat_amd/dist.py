@@ -62,7 +62,7 @@ def owner_of(frame, parts):
 
 def gather_objects(ctx, obj):
     """all-gather of small Python metadata (node captions, depths, frame ranges)."""
-    if ctx.world == 1:
+    if ctx.world == 1 and not (getattr(ctx, "always_collective", False) and dist.is_initialized()):
         return [obj]
     out = [None] * ctx.world
     dist.all_gather_object(out, obj)
@@ -70,7 +70,7 @@ def gather_objects(ctx, obj):
 
 
 def broadcast_object(ctx, obj, src=0):
-    if ctx.world == 1:
+    if ctx.world == 1 and not (getattr(ctx, "always_collective", False) and dist.is_initialized()):
         return obj
     box = [obj]
     dist.broadcast_object_list(box, src=src)

@@ -56,8 +56,11 @@ class Ref:
 
 
 class ShardedMemory:
-    def __init__(self, ctx, chunk_size=30, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5):
+    def __init__(self, ctx, chunk_size=30, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5, always_collective=False):
         self.ctx = ctx
+        # always_collective: take the collective code paths even where a shortcut exists (world size 1, rows already on the consumer) —
+        # lets a single-rank RCCL process group exercise exactly the calls an N-rank run makes (tests/test_gpu_sharded.py)
+        self.always_collective = always_collective
         self.chunk_size, self.num_clusters, self.interval = chunk_size, num_clusters, interval
         self.short_window, self.remember_window, self.tau = short_window, remember_window, tau
         self.store = {}             # (kind, id) -> local tensor [rows, P, D]
@@ -161,11 +164,11 @@ class ShardedMemory:
         mode "p2p": owners send their pieces straight to dst (the merge group when it straddles ranks)."""
         ctx = self.ctx
         pieces = [p for r in refs for p in r.pieces]
-        if ctx.world == 1:
+        if ctx.world == 1 and not self.always_collective:
             return U.cat_frames([self._local(p) for p in pieces])                    # adjacent bank rows: a view, no copy
         (P, D), dtype, dev = self.row_shape
         total = sum(p[4] - p[3] for p in pieces)
-        if all(p[0] == dst for p in pieces):                                         # nothing to move (e.g. C4's first ten chunks)
+        if all(p[0] == dst for p in pieces) and not (self.always_collective and mode == "allgather"):   # nothing to move (e.g. C4's first ten chunks)
             return U.cat_frames([self._local(p) for p in pieces]) if ctx.rank == dst else None
         if mode == "p2p":
             ops, out, off = [], None, 0
@@ -215,7 +218,7 @@ class ShardedMemory:
         """The root's retrieval decision (a list of Refs) to every rank as ONE small int64 tensor broadcast (no pickling):
         rows = (ref index, owner, kind, id, lo, hi), -1 padded."""
         ctx = self.ctx
-        if ctx.world == 1:
+        if ctx.world == 1 and not self.always_collective:
             return refs
         dev = self.row_shape[2]
         buf = torch.full((capacity, 6), -1, dtype=torch.int64)

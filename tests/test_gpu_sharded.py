@@ -79,3 +79,37 @@ def test_c5_multi_round_session_equals_single_stream_functions():
     mine = [got["mem"].fetch([n.centroids]) for n in got["tree"] if n.depth > 0]
     ref = [n.centroids for n in tree if n.depth > 0]
     assert len(mine) == 3 and all(torch.equal(a, b) for a, b in zip(mine, ref))
+
+
+def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
+    """A 1-rank RCCL ("nccl") process group on the GPU box: the sharded step with `always_collective` makes exactly the calls an
+    N-rank run makes (all_gather_object of captions, broadcast_object_list of the summary, the int64 Ref broadcast,
+    all_gather_into_tensor of the selected rows) and must still equal the single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    import bench
+    from streamchat_amd import dist as DD, sharded as SH
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ctx = DD.DistContext(0, 1, dev, "nccl")
+        ctx.always_collective = True
+        pipe = bench.Pipeline(dev, 440, with_llm=False, ctx=ctx)
+        a = pipe.step()
+        want = torch.cat([t.reshape(-1, t.shape[-1]) for t in list(a["short"]) + list(a["path_feats"])]).clone()
+        orig = SH.ShardedMemory.__init__
+
+        def forced(self, *args, **kw):
+            orig(self, *args, always_collective=True, **kw)
+        SH.ShardedMemory.__init__ = forced
+        try:
+            b = pipe.step_sharded()
+        finally:
+            SH.ShardedMemory.__init__ = orig
+        assert torch.equal(b["image_embeddings"], want) and list(b["path_text"]) == list(a["path_text"])
+        assert _describe(b["tree"]) == _describe(a["tree"])
+    finally:
+        dist.destroy_process_group()
