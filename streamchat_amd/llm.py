@@ -221,12 +221,13 @@ def _lib_pick_bytes(B):
 
 
 class DecodeGraph:
-    """Greedy batch-1 decode captured ONCE as a hipGraph and replayed per token (the 13 launches x layers of a decode step are
+    """Batch-1 decode (greedy, or temperature sampling: the reference's default, inference_streaming_longva_v2.py:252-253) captured ONCE as a hipGraph and replayed per token (the 13 launches x layers of a decode step are
     launch-bound from Python: cdna guide "capture launch-bound inner loops in hipGraphs").  Everything that changes from token to
     token lives in device memory: the input token id, the cache position (GEMV / RoPE write the KV row `pos`), the valid key count
     (attention takes it as kv_len over the full-capacity cache view), and the output token ring."""
 
-    def __init__(self, lm, max_new_tokens=1024, nsplit=None):
+    def __init__(self, lm, max_new_tokens=1024, nsplit=None, temperature=0.0):
+        self.temperature = float(temperature)           # > 0: sample from softmax(logits / T); the uniform draw is a graph-safe torch.rand inside the graph
         # split-KV factor: ~6 KV tiles per workgroup (49 k context: 128 splits = 2 workgroups per CU; measured 64: 243.5, 128: 247.9 tok/s)
         self.lm, self.nsplit = lm, (nsplit if nsplit else max(1, min(128, ((lm.cache_len + 63) // 64) // 6)))
         dev = lm.device
@@ -271,7 +272,10 @@ class DecodeGraph:
             m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
         logits = ops.gemv(lm.lm_head, h, None, out_f32=True, rms_gamma=lm.norm, rms_eps=c.eps)
-        nxt = ops.pick_token(logits, out=self.nxt, ws=self.ws_pick)          # HIP arg-max over the 152 064 logits (sampling.hip)
+        if self.temperature > 0:                                             # HIP temperature-softmax sample / arg-max over the 152 064 logits (sampling.hip)
+            nxt = ops.pick_token(logits, self.temperature, torch.rand(1, device=lm.device), out=self.nxt, ws=self.ws_pick)
+        else:
+            nxt = ops.pick_token(logits, out=self.nxt, ws=self.ws_pick)
         self.out.index_copy_(0, self.cnt, nxt)
         self.tok.copy_(nxt)
         self.pos.add_(1); self.len.add_(1); self.cnt.add_(1)
@@ -282,6 +286,15 @@ class DecodeGraph:
         self.tok.fill_(int(first_token)); self.pos.fill_(self.lm.cache_len); self.len.fill_(self.lm.cache_len + 1); self.cnt.zero_()
 
     def capture(self):
+        # the warm-up step and the capture itself draw from the default CUDA generator when sampling: put its state back afterwards, so
+        # that the tokens of a seeded run do not depend on whether the graph already existed
+        rng_state = torch.cuda.get_rng_state(self.lm.device)
+        try:
+            self._capture()
+        finally:
+            torch.cuda.set_rng_state(rng_state, self.lm.device)
+
+    def _capture(self):
         snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone())
         s = torch.cuda.Stream(device=self.lm.device)
         s.wait_stream(torch.cuda.current_stream(self.lm.device))
@@ -297,18 +310,32 @@ class DecodeGraph:
         for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
             t.copy_(v)
 
-    def run(self, n_tokens: int):
-        """n greedy tokens; returns them as a CPU list (one sync at the end) and advances lm.cache_len"""
+    def run(self, n_tokens: int, eos=(), check_every: int = 16):
+        """up to n tokens; returns them as a CPU list and advances lm.cache_len.  Without `eos` there is ONE host sync at the end;
+        with `eos` (ids that end the sequence, HF semantics: the EOS token is kept) the output ring is read every `check_every`
+        replays and the run stops at the first EOS — the few tokens decoded past it are dropped and the cache length rewound."""
         if not self.valid():
             raise RuntimeError("DecodeGraph: the KV cache was reallocated after capture; build a new DecodeGraph")
         if n_tokens > self.out.numel() or self.lm.cache_len + n_tokens > self.lm.cache[0].shape[0]:
             raise ValueError("DecodeGraph.run: more tokens than the output ring / KV cache can hold")
         if self.graph is None:
             self.capture()
-        for _ in range(n_tokens):
-            self.graph.replay()
-        toks = self.out[:n_tokens].cpu().tolist()
-        self.lm.cache_len += n_tokens
+        eos = set(eos)
+        done, toks = 0, []
+        while done < n_tokens:
+            step = n_tokens - done if not eos else min(check_every, n_tokens - done)
+            for _ in range(step):
+                self.graph.replay()
+            done += step
+            if eos:
+                toks = self.out[:done].cpu().tolist()
+                cut = next((i for i, t in enumerate(toks) if t in eos), None)
+                if cut is not None:
+                    toks, done = toks[:cut + 1], cut + 1
+                    break
+        if not eos:
+            toks = self.out[:done].cpu().tolist()
+        self.lm.cache_len += done                          # rows past an EOS stay in the cache but are never attended to again
         return toks
 
 
@@ -450,7 +477,7 @@ class LlavaQwenForCausalLM:
         self.device = lm.device
         self.eos_token_id = eos_token_id
         self.training = False
-        self._dg = None
+        self._dg, self._dgs = None, {}                      # decode graphs by sampling temperature (0.0 = greedy)
 
     def get_model(self):
         return types.SimpleNamespace(embed_tokens=self.lm.embed_tokens, mm_projector=getattr(self.frame_encoder, "projector", None))
@@ -500,12 +527,20 @@ class LlavaQwenForCausalLM:
         if top_p not in (None, 1.0):
             raise NotImplementedError("top_p sampling is not built (the reference passes top_p=None, inference_streaming_longva_v2.py:72)")
         eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])
-        if not (do_sample and temperature > 0) and not eos and max_new_tokens > 1 and kwargs.get("decode_graph", True):
-            first = int(ops.pick_token(logits).item())
-            if self._dg is None or self._dg.out.numel() < max_new_tokens or not self._dg.valid():
-                self._dg = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256))
-            self._dg.start(first)
-            rest = self._dg.run(max_new_tokens - 1)
+        sampling = bool(do_sample and temperature > 0)
+        if max_new_tokens > 1 and generator is None and kwargs.get("decode_graph", True):
+            # the token loop runs as a replayed hipGraph for greedy AND for the reference's default temperature sampling (the uniform
+            # draws come from the default CUDA generator inside the graph); a user `generator` selects the eager loop below
+            first = int(ops.pick_token(logits, temperature, torch.rand(1, device=self.device)).item()) if sampling else int(ops.pick_token(logits).item())
+            if first in eos:
+                return torch.tensor([[first]], dtype=torch.long, device=self.device)
+            key = round(float(temperature), 6) if sampling else 0.0
+            dg = self._dgs.get(key)
+            if dg is None or dg.out.numel() < max_new_tokens or not dg.valid():
+                dg = self._dgs[key] = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256), temperature=key)
+            self._dg = dg
+            dg.start(first)
+            rest = dg.run(max_new_tokens - 1, eos=eos)
             return torch.tensor([[first] + rest], dtype=torch.long, device=self.device)
         new = []
         for step in range(max_new_tokens):

@@ -277,3 +277,34 @@ def test_decode_graph_at_7b_widths_long_context_matches_eager():
         toks_eager.append(tok)
     assert toks_graph == toks_eager and lm_a.cache_len == lm_b.cache_len == S + 6
     torch.testing.assert_close(dg.logits.float().view(-1), logits.float().view(-1), rtol=2e-3, atol=2e-3)
+
+
+def test_generate_graph_path_sampling_and_eos():
+    """generate_with_image_embedding runs its token loop as a replayed hipGraph for greedy AND temperature sampling, and stops at EOS:
+    (a) EOS = the 4th greedy token -> exactly 4 tokens, EOS included (HF semantics), the cache length is rewound to it;
+    (b) temperature 1e-3 sampling == greedy; (c) sampling is reproducible under torch.manual_seed and differs across seeds at T = 2;
+    (d) the eager loop (decode_graph=False) gives the same greedy / EOS result."""
+    d, sd, cfg = _tiny()
+    greedy = d["greedy"].tolist()
+    ids = torch.arange(5, 12).unsqueeze(0)
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+
+    def gen(model, **kw):
+        model.prepare_inputs_embeddings_for_multimodal = lambda *a, **k: (None, None, None, None, emb.unsqueeze(0), None)     # the golden prompt
+        return model.generate_with_image_embedding(ids, image_embeddings=None, **kw)[0].tolist()
+    m = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, max_seq=128))
+    assert gen(m, do_sample=False, max_new_tokens=8) == greedy
+    eos_tok = greedy[3]
+    first_eos = greedy.index(eos_tok)
+    m_eos = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, max_seq=128), eos_token_id=[eos_tok, 511])
+    out = gen(m_eos, do_sample=False, max_new_tokens=8)
+    assert out == greedy[:first_eos + 1]
+    assert m_eos.lm.cache_len == 37 + first_eos                     # prompt + the tokens fed back (the EOS itself is not fed)
+    assert gen(m_eos, do_sample=False, max_new_tokens=8, decode_graph=False) == out
+    assert gen(m_eos, do_sample=False, max_new_tokens=8) == out     # the graph is reused after an early stop
+    assert gen(m, do_sample=True, temperature=1e-3, max_new_tokens=8) == greedy
+    torch.manual_seed(5); a = gen(m, do_sample=True, temperature=2.0, max_new_tokens=12)
+    torch.manual_seed(5); b = gen(m, do_sample=True, temperature=2.0, max_new_tokens=12)
+    torch.manual_seed(6); c = gen(m, do_sample=True, temperature=2.0, max_new_tokens=12)
+    assert a == b and a != c and len(a) == 12 and all(0 <= t < 512 for t in a)
+    assert set(m._dgs) == {0.0, 0.001, 2.0}
