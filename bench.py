@@ -315,6 +315,72 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
                        f"= {c1:.3f} frames/s")
 
 
+class PowerSampler:
+    """Package power and shader clock of this rank's GPU over the timed region, read from the amdgpu hwmon files (power1_input in uW,
+    freq1_input = sclk in Hz, power1_cap) every 0.25 s by a host thread: every dominant kernel of the step runs on the board's power
+    cap with the clock throttled below its 2.4 GHz boost, which is what `roofline.frac` against the nominal
+    peak cannot show.  No GPU work, no subprocess; None if the files are not there."""
+
+    def __init__(self, dev_index):
+        import glob
+        self.dir, self.samples, self._stop, self._th = None, [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        cands = []
+        for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            if os.path.exists(os.path.join(h, "power1_input")) and os.path.exists(os.path.join(h, "freq1_input")):
+                cands.append((os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))), h))
+        for pci, h in cands:
+            if want and pci.startswith(want):
+                self.dir = h
+        if self.dir is None and len(cands) == 1:
+            self.dir = cands[0][1]
+        self._cands = [h for _, h in cands]
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read().strip())
+
+    def _loop(self):
+        while not self._stop:
+            try:
+                if self.dir is None:        # PCI ids not exposed: the busy board is the one drawing the most power
+                    self.dir = max(self._cands, key=lambda h: self._read(os.path.join(h, "power1_input")))
+                self.samples.append((self._read(os.path.join(self.dir, "power1_input")) / 1e6, self._read(os.path.join(self.dir, "freq1_input")) / 1e6))
+            except Exception:
+                pass
+            time.sleep(0.25)
+
+    def __enter__(self):
+        if self.dir is not None or self._cands:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        w = [x[0] for x in self.samples]
+        c = [x[1] for x in self.samples]
+        cap = None
+        try:
+            cap = self._read(os.path.join(self.dir, "power1_cap")) / 1e6
+        except Exception:
+            pass
+        return dict(package_w_avg=round(sum(w) / len(w), 1), package_w_max=round(max(w), 1), cap_w=cap, sclk_mhz_avg=round(sum(c) / len(c)),
+                    sclk_mhz_min=round(min(c)), boost_mhz=2400, samples=len(w), source="amdgpu hwmon power1_input / freq1_input, 0.25 s period, timed region only")
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,7 +429,7 @@ def main():
     barrier()
     pipe.enc_events.clear()
     t0 = time.perf_counter()
-    with ops.KernelTimer() as kt:
+    with PowerSampler(local) as power, ops.KernelTimer() as kt:
         for _ in range(a.steps):
             run_step()
         barrier()
@@ -438,7 +504,7 @@ def main():
                config=dict(workload=names[config], context_tokens=pipe.last.get("context"), frames_total=n_total, frames_rank0=pipe.n,
                            micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""), weights="random-init"),
                encode_frames_per_s=round(enc_fps, 1), encode_ms_per_step=round(t_enc / a.steps * 1e3, 2),
-               roofline=roof, roofline_stages=stages, stages=per)
+               roofline=roof, roofline_stages=stages, stages=per, power=power.summary())
     if config == "C5":
         out["config"]["rounds"] = [dict(context=r.get("context"), top_level_nodes=len(r["top"]), frames_retrieved=sum(len(x) for x in r["wanted"]))
                                    for r in pipe.last["rounds"]]

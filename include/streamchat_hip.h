@@ -202,6 +202,12 @@ int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void*
                      const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
                      int o_head_stride, int64_t q_batch_stride, int64_t o_batch_stride, sc_stream_t stream);
 
+/* Which kernel sc_attention_f16 dispatches for a shape in this process: 0 = k_attn (32 queries per wave, whole 64-row tiles), 1 = k_attn
+ * long-prefill variant (Dh = 128, Sq >= 2048, no split-KV: 48 queries per wave, half tiles), 2 = k_attn_fat (the same shapes with
+ * SC_ATTN_FAT=1 in the environment: hand-scheduled v_mfma_f32_32x32x16_f16 loop, one wave per SIMD).  Host-only query for tests and
+ * profiles; the arithmetic contract of sc_attention_f16 does not depend on it. */
+int sc_attention_variant(int Dh, int Sq, int nsplit);
+
 /* Fused decode-step projection block: [q | k | v] = W . rmsnorm(x) + b, rotate-half RoPE (HF fp16 numerics) of q and k at position
  * pos[0] (device int32), q -> q_out [q_heads*Dh], k | v -> cache row pos[0] (row stride cache_ld, K at column 0, V at kv_heads*Dh).
  * One launch for the three small launches of a decode layer (q GEMV, kv GEMV, RoPE: HF Qwen2Attention q_proj / k_proj / v_proj +

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sc_rmsnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sc_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "sc_attention_variant": (c_int, [c_int, c_int, c_int]),
     "sc_bert_embed_ln_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_pool_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_avgpool_tokens_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

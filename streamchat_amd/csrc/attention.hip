@@ -19,6 +19,7 @@
 // steady-state loop with no mask, no row max and no O rescale (see the notes at the loop); what bounds it - LDS fragment
 // traffic and the SIMD issue port - is measured in tools/probes/ and summarised in DESIGN.md section 4.
 #include "sc_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -222,21 +223,24 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) * scale_log2;      // scale > 0: max commutes with scaling
     };
     // P = 2^(s*scale - m) -> fp16 MFMA operand + row sums (one packed FMA per pair of scores)
-    const sc_f2 sc2 = {scale_log2, scale_log2};
+    // scalar fp32 math on purpose (the file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (and
+    // v_dot2_f32_f16) do not execute under an MFMA of the same SIMD - each costs ~11 cycles of the matrix pipe, while up to four
+    // plain v_fma_f32 / v_add_f32 per MFMA are free (tools/probes/probe_fat.hip, profiles/r02_run30_probe_fat.log)
     auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC]) {
-        const sc_f2 m2 = {m_sub, m_sub};
-        sc_f2 ps2 = {0.f, 0.f};
+        const float nm = -m_sub;
+        float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kvb = 0; kvb < KVB; ++kvb)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const sc_f2 x = sc_f2{s[kvb][qb][r], s[kvb][qb][r + 1]} * sc2 - m2;
-                const sc_f2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                ps2 += p;
-                pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p[0];
-                pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p[1];
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, nm));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm));
+                ps0 += p0;
+                ps1 += p1;
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p0;
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p1;
             }
-        l_run[qb] += ps2[0] + ps2[1];
+        l_run[qb] += ps0 + ps1;
     };
     auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC]) {
 #pragma unroll
@@ -443,6 +447,20 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
 
 }  // namespace
 
+// attention_fat.hip: hand-scheduled long-prefill kernel (Dh = 128, 256 queries per workgroup, no split-KV)
+int sc_attn_fat_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv, int Hq, int Hkv,
+                       float scale, int causal, const int32_t* kv_len, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s);
+
+static bool attn_fat_enabled() {
+    static const bool fat = [] { const char* e = getenv("SC_ATTN_FAT"); return e && e[0] == '1'; }();
+    return fat;
+}
+
+extern "C" int sc_attention_variant(int Dh, int Sq, int nsplit) {
+    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return attn_fat_enabled() ? 2 : 1;
+    return 0;
+}
+
 extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
                                 int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
                                 int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, int64_t q_batch_stride,
@@ -467,8 +485,14 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     const long qbs = q_batch_stride > 0 ? (long)q_batch_stride : (long)Sq * ldq, obs = o_batch_stride > 0 ? (long)o_batch_stride : (long)Sq * ldo;
     SC_REQUIRE(qbs % 8 == 0 && obs % 4 == 0, "sc_attention_f16: batch strides must be multiples of 8 (q) / 4 (out)");
     if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
-    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles
-    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
+    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles.
+    // SC_ATTN_FAT=1 selects the hand-scheduled 32x32x16 kernel of attention_fat.hip instead: it keeps the matrix pipe 69 % busy
+    // against 57 %, but both kernels sit on the 1400 W package power cap (1.70 vs 1.87 GHz sustained) and deliver the same
+    // 1.17-1.19 PFLOP/s (tools/power_probe.py, profiles/r02_run31_power_probe.log), so the simpler kernel stays the default
+    if (sc_attention_variant(Dh, Sq, nsplit) == 2) {
+        return sc_attn_fat_launch(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, qhs, ohs, qbs, obs, s);
+    }
+    if (sc_attention_variant(Dh, Sq, nsplit) == 1) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
     if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
     return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
 }

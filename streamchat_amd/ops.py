@@ -324,6 +324,11 @@ def attention_workspace_bytes(B: int, Hq: int, Sq: int, nsplit: int, Dh: int) ->
     return B * Hq * Sq * nsplit * (Dh + 2) * 4 if nsplit > 1 else 0
 
 
+def attention_variant(Dh: int, Sq: int, nsplit: int = 1) -> int:
+    """Kernel sc_attention_f16 dispatches for this shape in this process (0 k_attn, 1 k_attn long-prefill variant, 2 k_attn_fat)."""
+    return int(_lib.load().sc_attention_variant(Dh, Sq, nsplit))
+
+
 def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1,
               q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None, ws=None):
     """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused

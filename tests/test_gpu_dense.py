@@ -1,4 +1,6 @@
 """GPU: MFMA GEMM + norms through the C ABI against a plain PyTorch fp32 reference of the same op."""
+import os
+
 import pytest
 import torch
 
@@ -165,6 +167,25 @@ def test_attention_late_huge_score_forces_the_exact_pass(Dh, causal):
     s_first = ((q[0, 400, :Dh].float() @ k[0, :64, :Dh].float().t()) * scale).max()
     assert (s_max - s_first) * 1.4427 > 20                                          # the test really is beyond fp16 range
     torch.testing.assert_close(out.float(), ref, rtol=3e-3, atol=3e-3)
+
+
+def test_attention_hand_scheduled_long_prefill_kernel_opt_in():
+    """SC_ATTN_FAT=1 routes Dh = 128 / Sq >= 2048 / unsplit attention to k_attn_fat (attention_fat.hip: one wave per SIMD, asm-scheduled
+    v_mfma_f32_32x32x16_f16 loop, masked-tile body, exact redo pass).  The switch is read once per process, so the long-prefill cases
+    and the late-huge-score case run again in a child process with the switch on; the child asserts that variant 2 is what runs."""
+    import subprocess
+    import sys
+    assert ops.attention_variant(128, 4096) in (1, 2) and ops.attention_variant(64, 4096) == 0 and ops.attention_variant(128, 4096, 4) == 0
+    code = ("import tests.test_gpu_dense as T\n"
+            "from streamchat_amd import ops\n"
+            "assert ops.attention_variant(128, 2048) == 2 and ops.attention_variant(128, 2047) == 0\n"
+            "for a in [(1, 2304, 2304, 4, 2, True, False), (2, 2050, 2500, 2, 2, False, True), (1, 2048, 3000, 7, 1, True, False), (1, 4100, 4100, 2, 1, True, False)]:\n"
+            "    T.test_attention_long_dh128_three_qblock_path(*a)\n"
+            "T.test_attention_late_huge_score_forces_the_exact_pass(128, True)\n"
+            "print('fat ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SC_ATTN_FAT": "1"}, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fat ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("N,K", [(3584, 3584), (1024, 3584), (152064, 3584), (3584, 18944), (130, 264)])
