@@ -386,16 +386,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SC_ALL_RANKS_ON_GPU0") == "1":      # testing on a 1-GPU box: every rank of the job shares device 0
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("SC_DIST_BACKEND", "nccl")     # "gloo": host-staged collectives, for N > 1 runs on a 1-GPU box (tests)
+        dist.init_process_group(backend, **(dict(device_id=torch.device(f"cuda:{local}")) if backend == "nccl" else {}))
     elif a.gpus > 1:
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    ctx = DD.DistContext(rank, world, dev, "nccl")
+    ctx = DD.DistContext(rank, world, dev, os.environ.get("SC_DIST_BACKEND", "nccl") if world > 1 else "nccl")
     config = a.config or ("C2" if a.no_llm else "C3")
     full = config in ("C3", "C4", "C5") and not a.no_llm
     if config == "C1":
@@ -505,6 +508,12 @@ def main():
                            micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""), weights="random-init"),
                encode_frames_per_s=round(enc_fps, 1), encode_ms_per_step=round(t_enc / a.steps * 1e3, 2),
                roofline=roof, roofline_stages=stages, stages=per, power=power.summary())
+    if pipe.last.get("path_text") is not None:      # what the question retrieved (and, on the sharded path, which global frames): equal for every GPU count
+        import zlib
+        sig = json.dumps(dict(path_text=list(pipe.last["path_text"]), wanted=pipe.last.get("wanted")))
+        out["config"]["retrieval_crc32"] = zlib.crc32(sig.encode())
+        if pipe.last.get("first_token") is not None:
+            out["config"]["first_token"] = int(pipe.last["first_token"][0, 0])
     if config == "C5":
         out["config"]["rounds"] = [dict(context=r.get("context"), top_level_nodes=len(r["top"]), frames_retrieved=sum(len(x) for x in r["wanted"]))
                                    for r in pipe.last["rounds"]]

@@ -75,3 +75,51 @@ def broadcast_object(ctx, obj, src=0):
     box = [obj]
     dist.broadcast_object_list(box, src=src)
     return box[0]
+
+
+# ---- tensor collectives.  On RCCL ("nccl") they run on the device tensors as they are.  The gloo backend has no device transport
+# for these, so device tensors are staged through the host: that is what lets the whole N > 1 code path (real HIP kernels, one
+# process per rank) run on a box with a single GPU in the tests; the CPU tests call the same functions with host tensors. ----
+def _staged(ctx, t):
+    return ctx.backend == "gloo" and t.is_cuda
+
+
+def all_gather_rows(ctx, recv, send):
+    """recv[world * n] <- every rank's send[n] (one all_gather_into_tensor of equal, right-sized slots)."""
+    if _staged(ctx, send):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu())
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send)
+
+
+def broadcast_tensor(ctx, t, src=0):
+    if _staged(ctx, t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def exchange(ctx, sends, recvs):
+    """Point-to-point pieces in one batch: sends = [(tensor, dst)], recvs = [(tensor view to fill, src)]; matching order on both ends."""
+    stage = any(_staged(ctx, t) for t, _ in sends + recvs)
+    keep, ops = [], []
+    for t, dst in sends:
+        t = t.contiguous()
+        t = t.cpu() if stage else t
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, dst))
+    hosts = []
+    for t, src in recvs:
+        h = torch.empty(t.shape, dtype=t.dtype) if stage else t
+        hosts.append((t, h))
+        ops.append(dist.P2POp(dist.irecv, h, src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if stage:
+        for t, h in hosts:
+            t.copy_(h)

@@ -21,10 +21,9 @@ The retrieved-frame indices, tree shape and texts therefore do not depend on the
 (tests/test_sharded_gloo.py: world 2 and 4 == the single-stream `updating_memory_buffer` on the same stream)."""
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import utiles as U
-from .dist import broadcast_object, gather_objects, partition_chunks
+from .dist import all_gather_rows, broadcast_object, broadcast_tensor, exchange, gather_objects, partition_chunks
 
 BANK, MERGE = 0, 1          # store key kinds: ("bank", segment) frame features / ("merge", node id) k-means centroids
 
@@ -171,7 +170,7 @@ class ShardedMemory:
         if all(p[0] == dst for p in pieces) and not (self.always_collective and mode == "allgather"):   # nothing to move (e.g. C4's first ten chunks)
             return U.cat_frames([self._local(p) for p in pieces]) if ctx.rank == dst else None
         if mode == "p2p":
-            ops, out, off = [], None, 0
+            sends, recvs, out, off = [], [], None, 0
             if ctx.rank == dst:
                 out = torch.empty((total, P, D), dtype=dtype, device=dev)
             for p in pieces:
@@ -180,13 +179,11 @@ class ShardedMemory:
                     if p[0] == dst:
                         out[off:off + n].copy_(self._local(p))
                     else:
-                        ops.append(dist.P2POp(dist.irecv, out[off:off + n], p[0]))
+                        recvs.append((out[off:off + n], p[0]))
                 elif p[0] == ctx.rank:
-                    ops.append(dist.P2POp(dist.isend, self._local(p).contiguous(), dst))
+                    sends.append((self._local(p), dst))
                 off += n
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            exchange(ctx, sends, recvs)
             return out
         # ---- all-gather: rank r packs its pieces (in order) into slot r of a [world, cap] buffer ----
         counts = [0] * ctx.world
@@ -203,7 +200,7 @@ class ShardedMemory:
                 n = p[4] - p[3]
                 send[k:k + n].copy_(self._local(p))
                 k += n
-        dist.all_gather_into_tensor(recv, send)                  # RCCL: every peer pushes its slot over its own xGMI link
+        all_gather_rows(ctx, recv, send)                         # RCCL: every peer pushes its slot over its own xGMI link
         if ctx.rank != dst:
             return None
         slot, views = [0] * ctx.world, []
@@ -229,7 +226,7 @@ class ShardedMemory:
             if rows:
                 buf[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
         buf = buf.to(dev)
-        dist.broadcast(buf, src=src)
+        broadcast_tensor(ctx, buf, src=src)
         rows = buf.cpu().tolist()
         out = {}
         for i, *p in rows:

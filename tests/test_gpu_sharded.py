@@ -113,3 +113,31 @@ def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
         assert _describe(b["tree"]) == _describe(a["tree"])
     finally:
         dist.destroy_process_group()
+
+
+def _bench_json(args, env, nproc=1):
+    import json
+    import subprocess
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29533"]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env={**os.environ, **env}, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(lines[0])
+
+
+def test_two_processes_through_torchrun_retrieve_and_prefill_like_one():
+    """The whole `bench.py --gpus 2` job as the driver launches it (torch.distributed.run, one process per rank, real HIP kernels in both,
+    7B prefill on rank 0), on this 1-GPU box: both ranks share device 0 (SC_ALL_RANKS_ON_GPU0) and the collectives go through gloo with
+    host staging (SC_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  The 880-frame stream straddles the ranks inside its
+    merge group (frames 0..399 over ranks owning [0, 440) and [440, 880)), so the P2P fetch, the all-gather of the selected rows, the
+    Ref broadcast and the caption exchange all carry data.  Retrieved frames, path text and the first generated token must equal the
+    1-process run of the same stream."""
+    common = ["--config", "C4", "--frames", "880", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
+    one = _bench_json(common + ["--force-sharded"], {})
+    two = _bench_json(common + ["--gpus", "2"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=2)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    for k in ("retrieval_crc32", "first_token", "context_tokens"):
+        assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
