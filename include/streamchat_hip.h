@@ -230,6 +230,21 @@ size_t sc_pick_token_workspace_bytes(int B);
 int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out,
                       void* ws, size_t ws_bytes, sc_stream_t stream);
 
+/* Next token with the logits processors / warpers HF `generate` applies when the checkpoint's generation_config.json (or the caller)
+ * asks for them - RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, in that order
+ * (transformers generation/logits_process.py; reference call site inference_streaming_longva_v2.py:252-256, utiles.py:551-556) - and
+ * one draw, all on the device (no host sync, hipGraph-capturable):
+ *   logits [B, V] fp32, row stride ld; MODIFIED in place when repetition_penalty != 1 (x < 0 ? x * r : x / r at every DISTINCT id of
+ *   prev_ids[row, 0 .. n_prev): the ids generated so far; n_prev_dev [B] device int32 or NULL -> n_prev_host for every row).
+ *   temperature <= 0: arg-max of the processed logits (lowest index on ties); else a sample from softmax(logits / T) restricted to
+ *   the top_k largest (0 = off; at most 64; tokens equal to the k-th value stay, as in HF) and to the nucleus top_p (1 = off; needs
+ *   top_k >= 1: SC_ERR_UNSUPPORTED otherwise), by inverse CDF at u[B] over the kept tokens in index order.
+ *   top_k = 0 and top_p = 1 is sc_pick_token_f32 after the penalty.  ws: sc_sample_token_workspace_bytes(B). */
+size_t sc_sample_token_workspace_bytes(int B);
+int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, float temperature, int top_k, float top_p, float repetition_penalty,
+                        const int64_t* prev_ids, int64_t prev_ld, const int32_t* n_prev_dev, int n_prev_host, const float* u,
+                        int64_t* out, void* ws, size_t ws_bytes, sc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

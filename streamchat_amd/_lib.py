@@ -50,6 +50,9 @@ SIGNATURES = {
     "sc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_pick_token_workspace_bytes": (c_size_t, [c_int]),
     "sc_pick_token_f32": (c_int, [c_void_p, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_sample_token_workspace_bytes": (c_size_t, [c_int]),
+    "sc_sample_token_f32": (c_int, [c_void_p, c_int, c_int, c_int64, c_float, c_int, c_float, c_float, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "sc_sim_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

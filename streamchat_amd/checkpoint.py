@@ -142,6 +142,9 @@ def load_longva(model_path, device="cuda", vision_tower_path=None, max_seq=65536
     del sd
     tok = load_tokenizer(model_path) if tokenizer else None
     model = LM.LlavaQwenForCausalLM(lm, enc, eos_token_id=_eos_ids(model_path, cfg, tok))
+    gc = os.path.join(model_path, "generation_config.json")      # what HF's generate falls back to for arguments the caller does not pass
+    if os.path.isfile(gc):
+        model.generation_config = {k: v for k, v in json.load(open(gc)).items() if k in ("temperature", "top_k", "top_p", "repetition_penalty", "do_sample")}
     return model, tok, vc
 
 

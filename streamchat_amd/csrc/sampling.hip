@@ -10,6 +10,18 @@
 //                   found by a scan over the block partials, then ONE block-wide prefix scan over that slice (<= 4 KiB elements)
 //                   locates the element.  Deterministic for a given u; u comes from the caller's (torch) generator.
 // HBM/L2 traffic = one read of the logits (608 KB per row) + a re-read of one slice: latency bound (~10 us), 0.3 % of a decode step.
+//
+// sc_sample_token_f32 adds what HF `generate` applies when the checkpoint's generation_config.json asks for it (Qwen2-7B-Instruct
+// ships repetition_penalty 1.05, top_k 20, top_p 0.8; the reference passes temperature and top_p explicitly, inference_streaming_
+// longva_v2.py:252-256, and inherits the rest): RepetitionPenaltyLogitsProcessor -> TemperatureLogitsWarper -> TopKLogitsWarper ->
+// TopPLogitsWarper, then one draw.  Three more launches, all on the device:
+//   k_rep_penalty   one block per row: every DISTINCT previously generated id is penalised once (x < 0 ? x * r : x / r), as HF's
+//                   gather / scatter does; an LDS bitmap over the vocabulary deduplicates.
+//   k_topk_partial  grid (NBLK, B): the slice goes to LDS, top_k rounds of block arg-max (lowest index on ties) -> k candidates.
+//   k_topk_final    one block per row: the NBLK * k candidates -> the k largest in descending order (+ further candidates equal to
+//                   the k-th value: HF keeps ties), softmax at temperature T, nucleus cut (remove the ascending-cumulative tail
+//                   <= 1 - top_p, keep >= 1), then the inverse CDF at u over the kept tokens IN INDEX ORDER (the convention of
+//                   sc_pick_token_f32, so that top_k >= V / top_p = 1 reproduce it).
 #include "sc_common.h"
 
 namespace {
@@ -129,6 +141,133 @@ __global__ __launch_bounds__(THREADS) void k_pick_final(const float* __restrict_
     }
 }
 
+
+// ---- HF logits processors / warpers ----
+constexpr int TK_MAX = 64;        // top_k limit
+constexpr int TK_KEEP = 128;      // kept tokens incl. ties at the k-th value
+struct Cand { float v; int i; };
+
+__global__ __launch_bounds__(THREADS) void k_rep_penalty(float* __restrict__ logits, int V, int64_t ld, const int64_t* __restrict__ prev, int64_t prev_ld,
+                                                         const int32_t* __restrict__ n_prev_dev, int n_prev_host, float pen) {
+    extern __shared__ unsigned bitmap[];
+    const int row = blockIdx.x;
+    const int n = n_prev_dev ? n_prev_dev[row] : n_prev_host;
+    const int words = (V + 31) >> 5;
+    for (int i = threadIdx.x; i < words; i += THREADS) bitmap[i] = 0u;
+    __syncthreads();
+    float* x = logits + (size_t)row * (size_t)ld;
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const int64_t id = prev[(size_t)row * (size_t)prev_ld + i];
+        if (id < 0 || id >= V) continue;
+        const unsigned bit = 1u << (id & 31);
+        if (atomicOr(&bitmap[id >> 5], bit) & bit) continue;             // a repeated id is penalised once (HF: gather, then scatter)
+        const float v = x[id];
+        x[id] = v < 0.f ? v * pen : v / pen;
+    }
+}
+
+// block-wide arg-best of (v, i) over all threads; every thread returns the winner
+__device__ __forceinline__ void block_best(float& bv, int& bi, float* sv, int* si) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) better(bv, bi, __shfl_xor(bv, s, 64), __shfl_xor(bi, s, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                                      // the previous round's readers are done with sv / si
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) better(bv, bi, sv[w], si[w]);
+}
+
+__global__ __launch_bounds__(THREADS) void k_topk_partial(const float* __restrict__ logits, int V, int64_t ld, int k, Cand* __restrict__ cand) {
+    extern __shared__ float sl[];
+    __shared__ float sv[THREADS / 64];
+    __shared__ int si[THREADS / 64];
+    const int row = blockIdx.y, blk = blockIdx.x;
+    const float* x = logits + (size_t)row * (size_t)ld;
+    const int per = ((V + NBLK - 1) / NBLK + 3) & ~3;
+    const int lo = blk * per, hi = min(V, lo + per), n = max(hi - lo, 0);
+    for (int i = threadIdx.x; i < n; i += THREADS) sl[i] = x[lo + i];
+    __syncthreads();
+    Cand* out = cand + ((size_t)row * NBLK + blk) * (size_t)k;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < n; i += THREADS) better(bv, bi, sl[i], i);
+        block_best(bv, bi, sv, si);
+        if (threadIdx.x == 0) {
+            out[r] = Cand{bv, bi == 0x7fffffff ? 0x7fffffff : lo + bi};
+            if (bi != 0x7fffffff) sl[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void k_topk_final(const Cand* __restrict__ cand, int k, float inv_t, float top_p, const float* __restrict__ u,
+                                                        int64_t* __restrict__ out) {
+    extern __shared__ Cand pool[];                                        // NBLK * k candidates
+    __shared__ float sv[THREADS / 64];
+    __shared__ int si[THREADS / 64];
+    __shared__ Cand top[TK_KEEP];
+    __shared__ float prob[TK_KEEP];
+    __shared__ int n_top;
+    const int row = blockIdx.x, total = NBLK * k;
+    const Cand* c = cand + (size_t)row * (size_t)total;
+    for (int i = threadIdx.x; i < total; i += THREADS) pool[i] = c[i];
+    __syncthreads();
+    // the k largest in descending order (equal values: lowest vocabulary index first), then everything equal to the k-th value
+    for (int r = 0; r < TK_KEEP; ++r) {
+        float bv = -INFINITY; int bi = 0x7fffffff, bp = 0;
+        for (int i = threadIdx.x; i < total; i += THREADS) {
+            const float v = pool[i].v; const int idx = pool[i].i;
+            if (v > bv || (v == bv && idx < bi)) { bv = v; bi = idx; bp = i; }
+        }
+        // reduce on (v, index); the pool slot of the winner is found again by its (unique) vocabulary index
+        float wv = bv; int wi = bi;
+        block_best(wv, wi, sv, si);
+        const bool stop = (wi == 0x7fffffff) || (r >= k && wv < top[k - 1].v);
+        if (stop) { if (threadIdx.x == 0) n_top = r; break; }
+        if (bi == wi && bv == wv) pool[bp].v = -INFINITY, pool[bp].i = 0x7fffffff;     // exactly one thread owns the winner
+        if (threadIdx.x == 0) { top[r] = Cand{wv, wi}; n_top = r + 1; }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int n = n_top;
+    if (n == 0) { if (threadIdx.x == 0) out[row] = 0; return; }
+    if (inv_t <= 0.f || u == nullptr) { if (threadIdx.x == 0) out[row] = top[0].i; return; }          // arg-max of the processed logits
+    if (threadIdx.x < n) prob[threadIdx.x] = __expf((top[threadIdx.x].v - top[0].v) * inv_t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int j = 0; j < n; ++j) tot += prob[j];
+        int keep = n;
+        if (top_p < 1.f) {                                                // HF TopPLogitsWarper: drop the ascending tail whose cumulative probability <= 1 - top_p
+            float tail = 0.f;
+            const float cut = (1.f - top_p) * tot;
+            for (int j = n - 1; j >= 1; --j) {
+                tail += prob[j];
+                if (tail <= cut) keep = j; else break;
+            }
+        }
+        // insertion sort of the kept tokens by vocabulary index (keep <= 128, typically <= 20), then the CDF walk
+        for (int a = 1; a < keep; ++a) {
+            const Cand ca = top[a]; const float pa = prob[a];
+            int b = a - 1;
+            while (b >= 0 && top[b].i > ca.i) { top[b + 1] = top[b]; prob[b + 1] = prob[b]; --b; }
+            top[b + 1] = ca; prob[b + 1] = pa;
+        }
+        float kept = 0.f;
+        for (int j = 0; j < keep; ++j) kept += prob[j];
+        const float target = fminf(fmaxf(u[row], 0.f), 0.99999994f) * kept;
+        float run = 0.f;
+        int pick = top[0].i;
+        for (int j = 0; j < keep; ++j) {
+            pick = top[j].i;
+            if (target < run + prob[j]) break;
+            run += prob[j];
+        }
+        out[row] = pick;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t sc_pick_token_workspace_bytes(int B) { return B > 0 ? (size_t)B * NBLK * sizeof(Part) : 0; }
@@ -145,5 +284,38 @@ extern "C" int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, 
     hipLaunchKernelGGL(k_pick_partial, dim3(NBLK, B), dim3(THREADS), 0, s, logits, V, ld, inv_t, (Part*)ws);
     hipLaunchKernelGGL(k_pick_final, dim3(B), dim3(THREADS), 0, s, logits, V, ld, inv_t, temperature > 0.f ? u : nullptr, (const Part*)ws, out);
     SC_CHECK_LAUNCH("sc_pick_token_f32");
+    return SC_OK;
+}
+
+extern "C" size_t sc_sample_token_workspace_bytes(int B) {
+    return B > 0 ? sc_align_up(sc_pick_token_workspace_bytes(B), 256) + (size_t)B * NBLK * TK_MAX * sizeof(Cand) : 0;
+}
+
+extern "C" int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, float temperature, int top_k, float top_p, float repetition_penalty,
+                                   const int64_t* prev_ids, int64_t prev_ld, const int32_t* n_prev_dev, int n_prev_host, const float* u, int64_t* out,
+                                   void* ws, size_t ws_bytes, sc_stream_t stream) {
+    SC_REQUIRE(logits && out && ws, "sc_sample_token_f32: null pointer argument");
+    SC_REQUIRE(B > 0 && V > 0 && ld >= V, "sc_sample_token_f32: bad sizes");
+    SC_REQUIRE(top_k >= 0 && top_k <= TK_MAX, "sc_sample_token_f32: top_k must be in [0, %d] (0 = off)", TK_MAX);
+    SC_REQUIRE(top_p > 0.f && repetition_penalty > 0.f, "sc_sample_token_f32: top_p and repetition_penalty must be positive");
+    SC_REQUIRE(!(temperature > 0.f) || u, "sc_sample_token_f32: sampling (temperature > 0) needs the uniform draws u[B]");
+    if (top_p < 1.f && top_k == 0)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_sample_token_f32: top_p < 1 needs 1 <= top_k <= %d (the nucleus is cut inside the top-k candidates)", TK_MAX);
+    if (ws_bytes < sc_sample_token_workspace_bytes(B))
+        return sc_fail(SC_ERR_WORKSPACE, "sc_sample_token_f32: workspace %zu < required %zu", ws_bytes, sc_sample_token_workspace_bytes(B));
+    hipStream_t s = (hipStream_t)stream;
+    if (repetition_penalty != 1.f && prev_ids && (n_prev_dev || n_prev_host > 0)) {
+        const size_t bm = (size_t)((V + 31) / 32) * 4;
+        SC_REQUIRE(bm <= 64 * 1024, "sc_sample_token_f32: vocabulary too large for the repetition bitmap");
+        hipLaunchKernelGGL(k_rep_penalty, dim3(B), dim3(THREADS), bm, s, logits, V, ld, prev_ids, prev_ld, n_prev_dev, n_prev_host, repetition_penalty);
+    }
+    if (top_k == 0 || top_k >= V)
+        return sc_pick_token_f32(logits, B, V, ld, temperature, u, out, ws, ws_bytes, stream);
+    Cand* cand = (Cand*)((char*)ws + sc_align_up(sc_pick_token_workspace_bytes(B), 256));
+    const int per = ((V + NBLK - 1) / NBLK + 3) & ~3;
+    const float inv_t = temperature > 0.f ? 1.0f / temperature : 0.f;
+    hipLaunchKernelGGL(k_topk_partial, dim3(NBLK, B), dim3(THREADS), (size_t)per * sizeof(float), s, logits, V, ld, top_k, cand);
+    hipLaunchKernelGGL(k_topk_final, dim3(B), dim3(THREADS), (size_t)NBLK * top_k * sizeof(Cand), s, cand, top_k, inv_t, top_p, temperature > 0.f ? u : nullptr, out);
+    SC_CHECK_LAUNCH("sc_sample_token_f32");
     return SC_OK;
 }

