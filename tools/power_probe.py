@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Sustained launches of one hot kernel while sampling the package power and the shader clock (rocm-smi): shows which kernels sit on
-the board's power cap.  usage: python tools/power_probe.py attn49k|attn49k_fat|gemm_llm|gemm_vit|vit_attn|idle [seconds]"""
+the board's power cap.  usage: python tools/power_probe.py attn49k|attn49k_fat|gemm_llm|gemm_llm_8wave|gemm_vit|vit_attn|decode|idle [seconds]"""
 import os, subprocess, sys, threading, time
 what = sys.argv[1] if len(sys.argv) > 1 else "attn49k"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 if what == "attn49k_fat":
     os.environ["SC_ATTN_FAT"] = "1"
+elif what == "gemm_llm_8wave":
+    os.environ["SC_GEMM_FAT"] = "0"           # the 8-wave k_gemm256 instead of the hand-scheduled 4-wave k_gemm_fat
 elif what == "attn49k":
     os.environ["SC_ATTN_FAT"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,8 +36,15 @@ elif what == "vit_attn":
     B, S, H, Dh = 512, 577, 16, 64
     q, k, v = r(B, S, H * Dh), r(B, S, H * Dh), r(B, S, H * Dh); out = torch.empty_like(q)
     fn = lambda: ops.attention(q, k, v, H, H, Dh, Dh ** -0.5, False, out=out); flops = 4.0 * B * H * S * S * Dh
-elif what in ("gemm_llm", "gemm_vit"):
-    M, N, K = (48994, 3584, 18944) if what == "gemm_llm" else (295424, 4096, 1024)
+elif what == "decode":
+    from streamchat_amd import llm as LM
+    cfg = LM.Qwen2ConfigLite()
+    lm = LM.Qwen2Model(LM.random_qwen2_state_dict(cfg, device="cuda"), cfg, device="cuda", max_seq=49152 + 4096, consume=True)
+    lm.reset_cache(); lm.cache_len = 49152
+    dg = LM.DecodeGraph(lm, max_new_tokens=4096); dg.start(1); dg.capture()
+    fn = lambda: dg.graph.replay(); flops = 16.92e9          # bytes per token: the printed "TFLOP/s" column is GB/s / 1000 for this row
+elif what in ("gemm_llm", "gemm_vit", "gemm_llm_8wave"):
+    M, N, K = (295424, 4096, 1024) if what == "gemm_vit" else (48994, 3584, 18944)
     a, w = r(M, K), r(N, K) * (K ** -0.5); out = torch.empty(M, N, device="cuda", dtype=torch.float16)
     fn = lambda: ops.gemm(a, w, out=out); flops = 2.0 * M * N * K
 else:
