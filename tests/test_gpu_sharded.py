@@ -128,16 +128,17 @@ def _bench_json(args, env, nproc=1):
     return json.loads(lines[0])
 
 
-def test_two_processes_through_torchrun_retrieve_and_prefill_like_one():
-    """The whole `bench.py --gpus 2` job as the driver launches it (torch.distributed.run, one process per rank, real HIP kernels in both,
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_processes_through_torchrun_retrieve_and_prefill_like_one(nproc):
+    """The whole `bench.py --gpus N` job (N = 2, 4) as the driver launches it (torch.distributed.run, one process per rank, real HIP kernels in both,
     7B prefill on rank 0), on this 1-GPU box: both ranks share device 0 (SC_ALL_RANKS_ON_GPU0) and the collectives go through gloo with
     host staging (SC_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  The 880-frame stream straddles the ranks inside its
-    merge group (frames 0..399 over ranks owning [0, 440) and [440, 880)), so the P2P fetch, the all-gather of the selected rows, the
+    merge group (frames 0..399 over ranks owning [0, 440) and [440, 880) at N = 2; three ranks at N = 4), so the P2P fetch, the all-gather of the selected rows, the
     Ref broadcast and the caption exchange all carry data.  Retrieved frames, path text and the first generated token must equal the
     1-process run of the same stream."""
     common = ["--config", "C4", "--frames", "880", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
     one = _bench_json(common + ["--force-sharded"], {})
-    two = _bench_json(common + ["--gpus", "2"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=2)
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    two = _bench_json(common + ["--gpus", str(nproc)], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=nproc)
+    assert two["n_gpus"] == nproc and one["n_gpus"] == 1
     for k in ("retrieval_crc32", "first_token", "context_tokens"):
         assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
