@@ -166,6 +166,15 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+    // Row sums on the matrix pipe at head dim <= 64: one extra MFMA per (q-block, 32 kv rows) with an all-ones A operand gives
+    // sum_kv P[kv][q] in every row of a 16 x 16 accumulator (the fp16-rounded P, exactly what P.V uses; complete over the four lane
+    // groups, so no shuffles at the end).  At Dh = 64 the loop is bound by the VALU port (2.8 VALU per MFMA, the pipe 25-40 % busy):
+    // this trades 8 v_add per lane and chunk for half an MFMA.  At Dh = 128 the pipe (and the board's power) is the limit: VALU adds stay.
+    constexpr bool LSUM_MFMA = (DH <= 64);
+    sc_f4 ol[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) ol[qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    const sc_h8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 
     // split-KV: this block covers tiles [t_lo, t_hi)
     const int per = (nt + nsplit - 1) / nsplit;
@@ -235,12 +244,11 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
             for (int r = 0; r < 4; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, nm));
                 const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm));
-                ps0 += p0;
-                ps1 += p1;
+                if (!LSUM_MFMA) { ps0 += p0; ps1 += p1; }
                 pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p0;
                 pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p1;
             }
-        l_run[qb] += ps0 + ps1;
+        if (!LSUM_MFMA) l_run[qb] += ps0 + ps1;
     };
     auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC]) {
 #pragma unroll
@@ -256,6 +264,9 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][pc], o[db][qb], 0, 0, 0);
             }
+            if (LSUM_MFMA)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[qb][pc], ol[qb], 0, 0, 0);
         }
     };
     auto masked = [&](int t) {
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                         const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);       // 1 when the reference did not move, 0 at the start
                         m_run[qb] = m_new;
                         l_run[qb] *= alpha;
+                        if (LSUM_MFMA) ol[qb] *= alpha;
 #pragma unroll
                         for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
                         p_part(s, qb, m_use, pf);
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         float chk = 0.f;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            chk += l_run[qb] * 0.f;
+            chk += (LSUM_MFMA ? ol[qb][0] : l_run[qb]) * 0.f;
 #pragma unroll
             for (int db = 0; db < DB; ++db) chk += (o[db][qb][0] + o[db][qb][1] + o[db][qb][2] + o[db][qb][3]) * 0.f;        // inf, NaN -> NaN
         }
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
             for (int jj = 0; jj < QB; ++jj) o[i][jj] = sc_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+        for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; ol[qb] = sc_f4{0.f, 0.f, 0.f, 0.f}; }
         if (t_lo < t_hi) stage(0, t_lo);
         __syncthreads();
     }
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         float l = l_run[qb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        if (LSUM_MFMA) l = ol[qb][0];
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qr = qw0 + qb * 16 + rl;
         if (part) {            // split-KV partial: unnormalised O (fp32), running max (scaled log2 domain) and sum
