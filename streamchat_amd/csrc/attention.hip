@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     const int qw0 = qblk0 + wave * (QB * 16);
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
     const int coff = Skv - Sq;                    // causal: query i sits at kv position i + coff
+    const bool wave_live = qw0 < Sq;              // false: every query row of this wave is padding of the last q-block
+    const int qw_last = min(qw0 + QB * 16, Sq) - 1;
 
     int nt = (kv_valid + KVT - 1) / KVT;
     if (CAUSAL) {
@@ -202,7 +204,9 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     // cost 3 % (shorter MFMA bursts) and 192-query blocks waste a quarter of a 577-token ViT sequence, so short sequences keep
     // CH = 64 / QB = 2.
     constexpr int NCH = KVT / CH, KVB = CH / 16, PC = CH / 32;
-    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB]) {
+    // nkvb: the first nkvb 16-row blocks of the chunk hold a key this wave can see (KVB in the steady state: folds away); the MFMAs,
+    // exponentials and P.V k-steps of the other blocks are skipped (ragged last tile: 577 = 9 x 64 + 1 keys per ViT frame; causal diagonal)
+    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB], int nkvb) {
         constexpr int NKF = KVB * DS;
         const char* skc = sk + c * KVB * KBLK;
         sc_h8 kfr[2];
@@ -214,7 +218,8 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const sc_f4 acc = ds == 0 ? sc_f4{0.f, 0.f, 0.f, 0.f} : s[kvb][qb];
-                s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[i & 1], qf[qb][ds], acc, 0, 0, 0);
+                if (kvb < nkvb) s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[i & 1], qf[qb][ds], acc, 0, 0, 0);
+                else s[kvb][qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
@@ -235,24 +240,28 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     // scalar fp32 math on purpose (the file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (and
     // v_dot2_f32_f16) do not execute under an MFMA of the same SIMD - each costs ~11 cycles of the matrix pipe, while up to four
     // plain v_fma_f32 / v_add_f32 per MFMA are free (tools/probes/probe_fat.hip, profiles/r02_run30_probe_fat.log)
-    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC]) {
+    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC], int nkvb) {
         const float nm = -m_sub;
         float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kvb = 0; kvb < KVB; ++kvb)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, nm));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm));
+                float p0 = 0.f, p1 = 0.f;
+                if (kvb < nkvb) {
+                    p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, nm));
+                    p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm));
+                }
                 if (!LSUM_MFMA) { ps0 += p0; ps1 += p1; }
                 pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p0;
                 pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p1;
             }
         if (!LSUM_MFMA) l_run[qb] += ps0 + ps1;
     };
-    auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC]) {
+    auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC], int nkvb) {
 #pragma unroll
         for (int pc = 0; pc < PC; ++pc) {
+            if (2 * pc >= nkvb) continue;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const char* vp = sv + (c * PC + pc) * 32 * VROW + v_off[db];
@@ -288,8 +297,12 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                 const char* sk = smem + cur * STAGE;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
+                    if (!wave_live) break;                                            // no valid query row in this wave: staging and barriers only
+                    int nkvb = (kv_valid - (t * KVT + c * CH) + 15) >> 4;                // 16-row blocks with a valid key ...
+                    if (CAUSAL) nkvb = min(nkvb, ((qw_last + coff - (t * KVT + c * CH)) >> 4) + 1);      // ... that the wave's last query still sees
+                    nkvb = max(0, min(nkvb, KVB));
                     sc_f4 s[KVB][QB];
-                    s_part(sk, c, s);
+                    s_part(sk, c, s, nkvb);
                     sc_h8 pf[QB][PC];
                     const int kv_t0 = t * KVT + c * CH + g * 4;
 #pragma unroll
@@ -311,9 +324,9 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                         if (LSUM_MFMA) ol[qb] *= alpha;
 #pragma unroll
                         for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
-                        p_part(s, qb, m_use, pf);
+                        p_part(s, qb, m_use, pf, nkvb);
                     }
-                    pv_part(sk + TILE, c, pf);
+                    pv_part(sk + TILE, c, pf, nkvb);
                 }
                 __syncthreads();
                 ++t;
@@ -331,11 +344,11 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     sc_f4 s[KVB][QB];
-                    s_part(sk, c, s);
+                    s_part(sk, c, s, KVB);
                     sc_h8 pf[QB][PC];
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf);
-                    pv_part(sk + TILE, c, pf);
+                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf, KVB);
+                    pv_part(sk + TILE, c, pf, KVB);
                 }
                 __syncthreads();
                 ++t;
