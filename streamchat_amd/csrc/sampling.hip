@@ -309,7 +309,8 @@ extern "C" int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, floa
         SC_REQUIRE(bm <= 64 * 1024, "sc_sample_token_f32: vocabulary too large for the repetition bitmap");
         hipLaunchKernelGGL(k_rep_penalty, dim3(B), dim3(THREADS), bm, s, logits, V, ld, prev_ids, prev_ld, n_prev_dev, n_prev_host, repetition_penalty);
     }
-    if (top_k == 0 || top_k >= V)
+    if (top_k > V) top_k = V;                                          // HF: top_k = min(top_k, vocabulary)
+    if (top_k == 0 || (top_k == V && top_p >= 1.f))                       // nothing to cut: the plain arg-max / temperature sample
         return sc_pick_token_f32(logits, B, V, ld, temperature, u, out, ws, ws_bytes, stream);
     Cand* cand = (Cand*)((char*)ws + sc_align_up(sc_pick_token_workspace_bytes(B), 256));
     const int per = ((V + NBLK - 1) / NBLK + 3) & ~3;

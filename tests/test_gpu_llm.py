@@ -413,3 +413,21 @@ def test_generate_applies_generation_config_in_graph_and_eager_loops():
     assert a == b and len(a) == 24                                                       # graph sampling is reproducible under manual_seed
     override = gen(do_sample=False, repetition_penalty=None)
     assert override == plain                                                             # an explicit None switches the penalty off (HF semantics)
+
+
+def test_sample_token_edge_cases():
+    """Tiny vocabularies (fewer entries than slices), top_k >= V (falls back to the plain pick), an empty penalty set, -inf logits."""
+    g = torch.Generator().manual_seed(3)
+    for V, top_k in [(7, 3), (50, 64), (65, 64), (300, 1)]:
+        base = torch.randn(2, V, generator=g) * 2.0
+        base[1, V // 2] = float("-inf")
+        prev = torch.zeros((2, 4), dtype=torch.int64)
+        for T, top_p, pen, n_prev in [(0.0, 1.0, 1.2, 0), (0.8, 1.0, 1.2, 4), (0.8, 0.7, 1.0, 0)]:
+            for _ in range(4):
+                u = torch.rand(2, generator=g)
+                ref, margin = _hf_pick(base, prev[:, :n_prev], T, min(top_k, V), top_p, pen, u)
+                got = ops.sample_token(base.cuda().clone(), T, u.cuda() if T > 0 else None, top_k=top_k, top_p=top_p, repetition_penalty=pen,
+                                       prev_ids=prev.cuda(), n_prev=n_prev).cpu()
+                for b in range(2):
+                    if margin[b] > 1e-6:
+                        assert int(got[b]) == int(ref[b]), (V, top_k, T, top_p, pen, n_prev, b, int(got[b]), int(ref[b]))
