@@ -103,6 +103,17 @@ def test_tiny_longva_checkpoint_loads_and_reproduces_hf_golden(tmp_path, fmt, to
     assert ids.shape[1] == 5 and int(ids.max()) < 512
     out = model.generate_with_image_embedding(ids, image_embeddings=None, do_sample=False, max_new_tokens=6)
     assert out.shape[1] <= 6 and (1 not in out[0, :-1].tolist())
+    # generation_config.json: the defaults of generate (HF semantics) and a list of EOS ids
+    assert model.generation_config == {}
+    json.dump(dict(do_sample=True, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05, eos_token_id=[1, 7], bos_token_id=0),
+              open(os.path.join(d, "generation_config.json"), "w"))
+    m2, _, _ = CK.load_longva(d, device="cuda:0", max_seq=256, tokenizer=False)
+    assert m2.generation_config == dict(do_sample=True, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05) and m2.eos_token_id == [1, 7]
+    from streamchat_amd.llm import resolve_sampling
+    assert tuple(resolve_sampling(m2.generation_config, True, 0.2, None)) == (0.2, 20, 1.0, 1.05)       # the reference's call on such a checkpoint
+    torch.manual_seed(0)
+    sampled = m2.generate_with_image_embedding(ids, image_embeddings=None, do_sample=True, temperature=0.2, top_p=None, max_new_tokens=6)
+    assert 1 <= sampled.shape[1] <= 6 and all(0 <= t < 512 for t in sampled[0].tolist())
 
 
 @pytest.mark.gpu
