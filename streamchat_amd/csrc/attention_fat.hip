@@ -176,6 +176,13 @@ __global__ __launch_bounds__(256, 1) void k_attn_fat(const _Float16* __restrict_
     const float fzero = 0.f;
 
 #define FAT_PV(I, QQ, PAR) do { if (!(FAT_ABL & 16)) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o[(I) & 3][QQ]) : "v"(vf[I]), "v"(pf[PAR][QQ][(I) >> 2])); } while (0)
+// The last P.V MFMA of a loop pass / of the kernel, followed - when DRAIN != 0 - by ~130 cycles of s_nop INSIDE the same asm statement:
+// behind the loop hipcc moves accumulators between register tuples (v_accvgpr_mov / v_mov of O and S), and it cannot know that the MFMAs
+// of the last three slots are still in flight (found with 64 keys: one q-block lost the last chunk's P.V; at 2 k+ keys the error hid
+// under the tolerance).  A separate drain statement would not do: the moves may be scheduled in front of it.
+#define FAT_PV_DRAIN(I, QQ, PAR, DRAIN) do { if (!(FAT_ABL & 16)) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lfat_nd%=\n\t" \
+        "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n.Lfat_nd%=:" \
+        : "+a"(o[(I) & 3][QQ]) : "v"(vf[I]), "v"(pf[PAR][QQ][(I) >> 2]), "s"(DRAIN) : "scc"); } while (0)
 #define FAT_S(PAR, Q_, I) do { if (FAT_ABL & 32) break; if ((I) == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(s[PAR][Q_]) : "v"(kf[I]), "a"(qf[Q_][I])); \
                                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[PAR][Q_]) : "v"(kf[I]), "a"(qf[Q_][I])); } while (0)
 #define FAT_FENCE asm volatile("" ::: "memory")
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fat(const _Float16* __restrict_
         FAT_S(0, 1, i);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // asm MFMA results are read by VALU below
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]) : : "memory");     // asm MFMA results are read by VALU below (the statement owns them: no read can be scheduled in front of it)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         float tmax = -INFINITY;
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fat(const _Float16* __restrict_
     //        softmax(c): s[H_] -> pf[H_], l   (80 VALU: q-block 0 in the first 16 MFMA slots, q-block 1 in the last 16)
     //      MFMA order S(q0,j) PV(q0,j) S(q1,j) PV(q1,j): a dependent MFMA (the S accumulation over j) follows its producer three
     //      MFMAs later - back to back the result is not forwarded and nothing interlocks inside asm. ----
-    auto iter = [&](auto Hc, auto Mc, int t, const char* vsrc, const char* ksrc) {
+    auto iter = [&](auto Hc, auto Mc, int t, const char* vsrc, const char* ksrc, int last) {
         constexpr int H_ = decltype(Hc)::value, HN = H_ ^ 1;
         constexpr bool MASK = decltype(Mc)::value;
         float x[2][16], e[2][16];
@@ -250,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fat(const _Float16* __restrict_
         // MFMA issued just before it waits until that MFMA has read its operands - ~30-70 cycles with the matrix pipe idle behind it
         // (ablation: the 16 + 32 fragment reads of a tile cost 38 % of the loop when placed right behind their last use)
 #define FAT_M(K) do { if (((K) & 3) == 0) { FAT_S(HN, 0, (K) >> 2); if ((K) >= 4) rd_v(((K) >> 2) - 1, vsrc); } else if (((K) & 3) == 1) FAT_S(HN, 1, (K) >> 2); \
-                      else if (((K) & 3) == 2) { FAT_PV((K) >> 2, 0, HN); rd_k((K) >> 2, ksrc); } else FAT_PV((K) >> 2, 1, HN); } while (0)
+                      else if (((K) & 3) == 2) { FAT_PV((K) >> 2, 0, HN); rd_k((K) >> 2, ksrc); } \
+                      else if ((K) == 31 && H_ == 1) FAT_PV_DRAIN(7, 1, HN, last); else FAT_PV((K) >> 2, 1, HN); } while (0)
         // plain fp32 VALU only: v_pk_*_f32 and v_dot2_f32_f16 do not execute under an MFMA (tools/probes/probe_fat.hip)
 #define FAT_F(Q_, R) do { if (FAT_ABL & (8 | 64)) x[Q_][R] = s[H_][Q_][R]; else asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[Q_][R]) : "v"(s[H_][Q_][R]), "s"(scale_log2), "v"(nm[Q_])); } while (0)
 #define FAT_E(Q_, R) do { if (FAT_ABL & (8 | 128)) e[Q_][R] = x[Q_][R]; else asm volatile("v_exp_f32 %0, %1" : "=v"(e[Q_][R]) : "v"(x[Q_][R])); \
@@ -263,24 +271,30 @@ __global__ __launch_bounds__(256, 1) void k_attn_fat(const _Float16* __restrict_
     };
     // one tile = two chunks; on entry: all waves are done with tile t-1 (its ring slot takes tile t+3) and tile t+1 (DMA issued
     // during tile t-2) has landed - at most the 8 DMA instructions of tile t+2 stay in flight
-    auto tile = [&](auto Mc, int t) {
+    auto tile = [&](auto Mc, int t, int last_) {
+        const int last = __builtin_amdgcn_readfirstlane(last_);              // an SGPR for the s_cmp inside FAT_PV_DRAIN
         if (!(FAT_ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         const char* vs = smem + (t & 3) * F_STAGE;
         const char* ks = smem + ((t + 1) & 3) * F_STAGE;
-        iter(std::integral_constant<int, 0>{}, Mc, t, vs, ks);
-        iter(std::integral_constant<int, 1>{}, Mc, t, vs + 32 * 256, ks + 32 * 256);
+        iter(std::integral_constant<int, 0>{}, Mc, t, vs, ks, 0);
+        iter(std::integral_constant<int, 1>{}, Mc, t, vs + 32 * 256, ks + 32 * 256, last);
     };
     // two loops, not one loop with two bodies: around a branch inside the loop hipcc moves every accumulator between copies
-    for (int t = 0; t < n_full; ++t) tile(std::false_type{}, t);
-    for (int t = n_full; t < nt; ++t) tile(std::true_type{}, t);
+    for (int t = 0; t < n_full; ++t) tile(std::false_type{}, t, t + 1 == n_full);          // last pass of a loop: drain before the moves behind it
+    for (int t = n_full; t < nt; ++t) tile(std::true_type{}, t, t + 1 == nt);
     // drain: P.V of the last chunk (parity 1), then let the MFMA pipe and the DMA queue run empty (zero-fill DMA must not land in
     // the LDS of the workgroup that follows on this CU)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { FAT_PV(i, 0, 1); FAT_PV(i, 1, 1); }
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < 7; ++i) { FAT_PV(i, 0, 1); FAT_PV(i, 1, 1); }
+    FAT_PV(7, 0, 1);
+    FAT_PV_DRAIN(7, 1, 1, 1);
+    // ... and ONE statement that owns all eight accumulators: the epilogue's v_accvgpr_read of an O tile may otherwise be scheduled
+    // right behind that tile's last asm MFMA (in flight for another 64 cycles) - which is what happened to the four q-block-0 tiles
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)"
+                 : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[2][0]), "+a"(o[2][1]), "+a"(o[3][0]), "+a"(o[3][1]) : : "memory");
 
     // ---- overflow check (fp16 P beyond 2^16 of the reference -> inf / NaN in O or l) ----
     float chk = 0.f;

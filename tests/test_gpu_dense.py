@@ -182,6 +182,21 @@ def test_attention_hand_scheduled_long_prefill_kernel_opt_in():
             "for a in [(1, 2304, 2304, 4, 2, True, False), (2, 2050, 2500, 2, 2, False, True), (1, 2048, 3000, 7, 1, True, False), (1, 4100, 4100, 2, 1, True, False)]:\n"
             "    T.test_attention_long_dh128_three_qblock_path(*a)\n"
             "T.test_attention_late_huge_score_forces_the_exact_pass(128, True)\n"
+            "import random, torch\n"
+            "rnd = random.Random(7)\n"
+            "for case in range(10):\n"
+            "    B, Hkv = rnd.choice([1, 2]), rnd.choice([1, 2])\n"
+            "    Hq, causal = Hkv * rnd.choice([1, 3]), rnd.random() < 0.6\n"
+            "    Sq = rnd.randint(2048, 2500); Skv = Sq + rnd.choice([0, 0, 37, 700])\n"
+            "    q, k, v = T._rand((B, Sq, Hq * 128), 100 + case), T._rand((B, Skv, Hkv * 128), 200 + case), T._rand((B, Skv, Hkv * 128), 300 + case)\n"
+            "    k[:, Skv - 50:] = float('nan'); v[:, Skv - 50:] = float('nan')             # allocator garbage behind the valid rows\n"
+            "    kv_len = torch.tensor([rnd.choice([Skv - 50, Skv - 64, Skv - 113, 65, 64, 1]) for _ in range(B)], device='cuda', dtype=torch.int32)\n"
+            "    if causal: kv_len = torch.clamp(kv_len, min=Skv - 113)                       # causal: every query must keep a visible key\n"
+            "    out = ops.attention(q, k, v, Hq, Hkv, 128, 0.09, causal, kv_len)\n"
+            "    kk, vv = k.clone(), v.clone(); kk[:, Skv - 50:] = 0; vv[:, Skv - 50:] = 0\n"
+            "    ref = T._attn_ref(q, kk, vv, Hq, Hkv, 128, 0.09, causal, kv_len)\n"
+            "    ok = torch.isfinite(ref).all(-1)                                             # rows without any visible key are undefined in the reference\n"
+            "    torch.testing.assert_close(out.float()[ok], ref[ok], rtol=2e-3, atol=2e-3)\n"
             "print('fat ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SC_ATTN_FAT": "1"}, cwd=root, capture_output=True, text=True, timeout=600)
