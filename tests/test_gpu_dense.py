@@ -169,6 +169,36 @@ def test_attention_late_huge_score_forces_the_exact_pass(Dh, causal):
     torch.testing.assert_close(out.float(), ref, rtol=3e-3, atol=3e-3)
 
 
+def test_attention_randomised_shapes_and_padding():
+    """Seeded sweep over head dims, ragged query / key counts, GQA groups, causal offsets and per-batch key lengths at and around
+    multiples of 16 and 64 (the general-tile paths: dead key blocks skipped, dead waves of the last q-block, row sums on the matrix
+    pipe at head dim <= 64), NaN garbage behind the valid keys; against fp32 torch.  Rows without any visible key are not compared."""
+    import random
+    rnd = random.Random(11)
+    for case in range(28):
+        Dh = rnd.choice([32, 64, 64, 128])
+        B, Hkv = rnd.choice([1, 2, 3]), rnd.choice([1, 2])
+        Hq, causal = Hkv * rnd.choice([1, 2, 7]), rnd.random() < 0.5
+        Sq = rnd.choice([1, 15, 16, 17, 63, 64, 65, 127, 129, 300, 577, 640, rnd.randint(2, 700)])
+        Skv = Sq + rnd.choice([0, 0, 1, 63, 200]) if causal else rnd.choice([1, 16, 33, 64, 65, 128, 577, rnd.randint(1, 900)])
+        q, k, v = _rand((B, Sq, Hq * Dh), 500 + case), _rand((B, Skv, Hkv * Dh), 600 + case), _rand((B, Skv, Hkv * Dh), 700 + case)
+        kv_len = None
+        if rnd.random() < 0.6:
+            lens = [max(1, min(Skv, rnd.choice([Skv, Skv - 1, Skv - 15, Skv - 16, Skv - 17, Skv - 64, 1, 16, 17, 64, 65]))) for _ in range(B)]
+            if causal:
+                lens = [max(n, Skv - Sq + 1) for n in lens]                          # every query keeps at least its first key
+            kv_len = torch.tensor(lens, device="cuda", dtype=torch.int32)
+        kk, vv = k.clone(), v.clone()
+        if kv_len is not None:
+            for b in range(B):
+                k[b, lens[b]:] = float("nan"); v[b, lens[b]:] = float("nan"); kk[b, lens[b]:] = 0; vv[b, lens[b]:] = 0
+        out = ops.attention(q, k, v, Hq, Hkv, Dh, 0.11, causal, kv_len)
+        ref = _attn_ref(q, kk, vv, Hq, Hkv, Dh, 0.11, causal, kv_len)
+        ok = torch.isfinite(ref).all(-1)
+        assert torch.isfinite(out.float()[ok]).all(), (case, Dh, B, Sq, Skv, Hq, Hkv, causal)
+        torch.testing.assert_close(out.float()[ok], ref[ok], rtol=3e-3, atol=3e-3, msg=lambda m: f"case {case}: Dh={Dh} B={B} Sq={Sq} Skv={Skv} Hq={Hq} Hkv={Hkv} causal={causal} kv_len={None if kv_len is None else kv_len.tolist()}\n{m}")
+
+
 def test_attention_hand_scheduled_long_prefill_kernel_opt_in():
     """SC_ATTN_FAT=1 routes Dh = 128 / Sq >= 2048 / unsplit attention to k_attn_fat (attention_fat.hip: one wave per SIMD, asm-scheduled
     v_mfma_f32_32x32x16_f16 loop, masked-tile body, exact redo pass).  The switch is read once per process, so the long-prefill cases
