@@ -431,3 +431,19 @@ def test_sample_token_edge_cases():
                 for b in range(2):
                     if margin[b] > 1e-6:
                         assert int(got[b]) == int(ref[b]), (V, top_k, T, top_p, pen, n_prev, b, int(got[b]), int(ref[b]))
+
+
+def test_batched_generation_applies_the_same_processor_chain():
+    """BatchDecoder (the batched chunk captions) under a generation_config with a repetition penalty: every sequence of the batch must
+    equal its own single-sequence generate (graph and eager), i.e. the per-row history / counters feed sc_sample_token_f32 correctly."""
+    d = np.load(os.path.join(G, "qwen2_tiny.npz"))
+    cfg = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=512, rope_theta=1e6)
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("lm.")}
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, device="cuda", max_seq=256))
+    model.generation_config = dict(repetition_penalty=1.4, top_k=5)
+    prompts = [torch.tensor([[5, 9, 3, 7, 11, 2]]), torch.tensor([[8, 8, 1]]), torch.tensor([[5, 9, 3, 7, 11, 2]])]
+    single = [model.generate_with_image_embedding(p, image_embeddings=None, do_sample=False, max_new_tokens=12)[0].tolist() for p in prompts]
+    batch = model.generate_batch_with_image_embedding(prompts, [None] * 3, do_sample=False, max_new_tokens=12)
+    assert [b[0].tolist() for b in batch] == single and single[0] == single[2]
+    plain = LM.LlavaQwenForCausalLM(model.lm).generate_batch_with_image_embedding(prompts, [None] * 3, do_sample=False, max_new_tokens=12)
+    assert [b[0].tolist() for b in plain] != single                                       # the penalty really changes these sequences
