@@ -34,7 +34,17 @@ typedef void* sc_stream_t;
 enum { SC_F16 = 0, SC_BF16 = 1, SC_F32 = 2 };
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC_ERR_UNSUPPORTED = -4 };
 
-#define SC_ABI_VERSION 2   /* 2: sc_attention_f16 batch strides, sc_avgpool_tokens_f16 */
+/* ABI changelog (a binding asserts sc_abi_version() >= the version that introduced the newest symbol it uses):
+ *   1  first release
+ *   2  sc_attention_f16 gained batch strides; + sc_avgpool_tokens_f16
+ *   3  + sc_kmeans_update          (one centroid update from given labels: torch_kmeans / kmeans_pytorch host loops)
+ *      + sc_decode_qkv_f16         (q/k/v GEMV + RMSNorm + RoPE + KV-cache append in one launch)
+ *      + sc_pick_token_f32, sc_pick_token_workspace_bytes     (arg-max / temperature sampling on device)
+ *      + sc_sample_token_f32, sc_sample_token_workspace_bytes (repetition penalty / top-k / top-p chain)
+ *      + sc_attention_variant      (which attention kernel a shape is dispatched to)
+ *      (these seven shipped in round 2 under version 2 by mistake; 3 is the first version that guarantees them)
+ */
+#define SC_ABI_VERSION 3
 
 int sc_abi_version(void);
 const char* sc_last_error(void);

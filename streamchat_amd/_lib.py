@@ -16,7 +16,7 @@ class StreamChatHipError(RuntimeError):
 
 
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
-ABI_VERSION = 2            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
+ABI_VERSION = 3            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),

@@ -74,10 +74,12 @@ def read_state_dict(path, keep=None, dtype=torch.float16):
 
 
 def load_tokenizer(path):
-    """The checkpoint's own tokenizer (builder.py:93,177: AutoTokenizer.from_pretrained(model_path, use_fast=False)); local files only."""
+    """The checkpoint's own tokenizer (builder.py:93,177: AutoTokenizer.from_pretrained(model_path, use_fast=False)); local files only.
+    `use_fast=False` is passed like upstream: it selects the slow tokenizer on the reference's pinned transformers 4.37.2; transformers
+    >= 5 (installed here) only ships the fast classes and ignores the argument."""
     try:
         from transformers import AutoTokenizer
-        return AutoTokenizer.from_pretrained(path, local_files_only=True)
+        return AutoTokenizer.from_pretrained(path, use_fast=False, local_files_only=True)
     except Exception as e:
         raise CheckpointError(f"{path}: cannot load the tokenizer ({e})") from e
 

@@ -185,8 +185,10 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     // 3584-row projections (224 workgroups at 4 rows/wave left most CUs with a single latency-bound workgroup)
     const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
     static int rpw_few = -1;                        // SC_GEMV_RPW_FEW=1|2|4: rows per wave of the small projections (A/B runs)
-    if (rpw_few < 0) { const char* e = getenv("SC_GEMV_RPW_FEW"); rpw_few = e ? atoi(e) : 1; }
-    const int rpw = few ? rpw_few : 4;
+    if (rpw_few < 0) { const char* e = getenv("SC_GEMV_RPW_FEW"); const int v = e ? atoi(e) : 1; rpw_few = (v == 2 || v == 4) ? v : 1; }   // anything else -> 1
+    // the tuning knob only applies where a kernel for that row count is instantiated (fp16 output); the fp32-output path of a short
+    // projection always runs one row per wave, and the grid is derived from the rows per wave of the kernel actually launched
+    const int rpw = few ? (out_f32 ? 1 : rpw_few) : 4;
     const dim3 grid((unsigned)((N + 4 * rpw - 1) / (4 * rpw))), block(256);
     if (few && !out_f32 && (rpw == 2 || rpw == 4 || (rpw_few == 1 && K >= 8192))) {
         // long rows (the down projection, K = 18 944): two rows per wave and 8 x 16 B per lane in flight per row stream the 136 MB at

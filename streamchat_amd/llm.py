@@ -240,10 +240,12 @@ class Sampling(typing.NamedTuple):
 def resolve_sampling(generation_config, do_sample, temperature=_UNSET, top_p=_UNSET, top_k=_UNSET, repetition_penalty=_UNSET):
     """HF semantics (GenerationConfig.update): an argument the caller passes - even None - overrides the checkpoint's
     generation_config.json; one it does not pass falls back to that file, then to HF's defaults (temperature 1.0, top_k 50, top_p 1.0,
-    repetition_penalty 1.0).  The reference passes do_sample, temperature and top_p (inference_streaming_longva_v2.py:252-256, utiles.py:
+    repetition_penalty 1.0, do_sample False); `do_sample` follows the same rule.  The reference passes do_sample, temperature and top_p (inference_streaming_longva_v2.py:252-256, utiles.py:
     551-556) and inherits top_k and repetition_penalty.  None / 0 / 1.0 switch a stage off; the warpers only exist when sampling."""
     g = dict(temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0)
     g.update({k: v for k, v in (generation_config or {}).items() if k in g})
+    if do_sample is _UNSET or do_sample is None:        # not passed: the checkpoint's file decides, then HF's default (greedy)
+        do_sample = bool((generation_config or {}).get("do_sample", False))
     for k, v in (("temperature", temperature), ("top_p", top_p), ("top_k", top_k), ("repetition_penalty", repetition_penalty)):
         if v is not _UNSET:
             g[k] = v
@@ -557,7 +559,7 @@ class LlavaQwenForCausalLM:
         return None, new_pos, new_mask, past_key_values, out.unsqueeze(0), (None if labels is None else labels_out.unsqueeze(0))
 
     @torch.no_grad()
-    def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], do_sample=False, temperature=_UNSET,
+    def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], do_sample=_UNSET, temperature=_UNSET,
                                             max_new_tokens=256, generator=None, top_p=_UNSET, top_k=_UNSET, repetition_penalty=_UNSET, **kwargs):
         """B independent prompts (one `inputs` ids tensor and one image_embeddings list each, as for generate_with_image_embedding)
         decoded together by BatchDecoder.  Returns a list of B LongTensors [1, n_b] of new token ids."""
@@ -579,7 +581,7 @@ class LlavaQwenForCausalLM:
         return int(ops.sample_token(logits.clone(), sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=pv, n_prev=len(prev)).item())
 
     @torch.no_grad()
-    def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=False, temperature=_UNSET,
+    def generate_with_image_embedding(self, inputs=None, image_embeddings=None, modalities=["image"], do_sample=_UNSET, temperature=_UNSET,
                                       top_p=_UNSET, num_beams=1, max_new_tokens=256, use_cache=True, generator=None, top_k=_UNSET,
                                       repetition_penalty=_UNSET, **kwargs):
         """llava_qwen.py:137-155 -> Qwen2 generate(inputs_embeds=...).  Returns the NEW token ids [1, n] like HF does for

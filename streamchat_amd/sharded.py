@@ -19,6 +19,8 @@ Frame ranges are never exchanged: they follow from `partition_chunks`.  With wor
 
 The retrieved-frame indices, tree shape and texts therefore do not depend on the number of GPUs
 (tests/test_sharded_gloo.py: world 2 and 4 == the single-stream `updating_memory_buffer` on the same stream)."""
+import random
+
 import numpy as np
 import torch
 
@@ -68,6 +70,7 @@ class ShardedMemory:
         self.next_node = 0
         self.row_shape = None       # (P, D), dtype, device of a feature row
         self._send = self._recv = None
+        self.kmeans_max_iter = 10   # weighted_kmeans_feature's default (utiles.py:291): fixes how many reseed rows a merge draws
 
     # ---------------------------------------------------------------------------------------------
     def partition(self, n_frames):
@@ -131,13 +134,17 @@ class ShardedMemory:
             combined = Ref.concat([n.centroids for n in group])
             executor = combined.pieces[0][0]
             if combined.rows > self.num_clusters:
-                # every rank draws the init rows (keeps the CPU generator in lockstep with the 1-GPU run); only the executor clusters
+                # every rank draws the init rows AND the empty-cluster reseed rows (keeps the CPU torch generator and Python's global
+                # `random` state in lockstep with the 1-GPU run and with each other — the executor changes from merge to merge, so a
+                # draw taken only there would let the ranks' states drift apart); only the executor clusters
                 init_idx = torch.randperm(combined.rows)[:self.num_clusters]
+                reseed_idx = [random.randint(0, combined.rows - 1) for _ in range(self.kmeans_max_iter * self.num_clusters)]
                 X = self.fetch([combined], dst=executor, mode="p2p")
                 node_id = self.next_node
                 self.next_node += 1
                 if ctx.rank == executor:
-                    new_centroids, _ = U.weighted_kmeans_feature(X, self.num_clusters, init_idx=init_idx)
+                    new_centroids, _ = U.weighted_kmeans_feature(X, self.num_clusters, init_idx=init_idx, reseed_idx=reseed_idx,
+                                                                  max_iter=self.kmeans_max_iter)
                     self.store[(MERGE, node_id)] = new_centroids
                 new_ref = Ref([(executor, MERGE, node_id, 0, self.num_clusters)])
             else:
@@ -208,23 +215,29 @@ class ShardedMemory:
             n = p[4] - p[3]
             views.append(recv[p[0] * cap + slot[p[0]]: p[0] * cap + slot[p[0]] + n])
             slot[p[0]] += n
-        return U.cat_frames(views) if len(views) == 1 else torch.cat(views, dim=0)
+        # always a fresh tensor: `recv` is reused by the next fetch, so an alias of it (one piece -> one view) would be overwritten
+        # under a caller that holds two results
+        return views[0].clone() if len(views) == 1 else torch.cat(views, dim=0)
 
     # ---------------------------------------------------------------------------------------------
     def broadcast_refs(self, refs, src=0, capacity=64):
         """The root's retrieval decision (a list of Refs) to every rank as ONE small int64 tensor broadcast (no pickling):
-        rows = (ref index, owner, kind, id, lo, hi), -1 padded."""
+        rows = (ref index, owner, kind, id, lo, hi); preceded by a one-element broadcast of the row count."""
         ctx = self.ctx
         if ctx.world == 1 and not self.always_collective:
             return refs
         dev = self.row_shape[2]
-        buf = torch.full((capacity, 6), -1, dtype=torch.int64)
-        if ctx.rank == src:
-            rows = [(i,) + p for i, r in enumerate(refs) for p in r.pieces]
-            if len(rows) > capacity:
-                raise ValueError(f"{len(rows)} pieces exceed the broadcast capacity {capacity}")
-            if rows:
-                buf[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+        # the piece count travels first, so the table is sized by what the root actually selected (no capacity guess) and a bad
+        # selection raises on EVERY rank after the collective instead of leaving the others waiting inside it
+        rows = [(i,) + p for i, r in enumerate(refs) for p in r.pieces] if ctx.rank == src else []
+        n = torch.tensor([len(rows)], dtype=torch.int64).to(dev)
+        broadcast_tensor(ctx, n, src=src)
+        n = int(n.item())
+        if capacity is not None and n > capacity:
+            raise ValueError(f"{n} pieces exceed the broadcast capacity {capacity}")
+        if n == 0:
+            return []
+        buf = torch.tensor(rows, dtype=torch.int64).reshape(n, 6) if ctx.rank == src else torch.empty((n, 6), dtype=torch.int64)
         buf = buf.to(dev)
         broadcast_tensor(ctx, buf, src=src)
         rows = buf.cpu().tolist()

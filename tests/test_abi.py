@@ -26,12 +26,21 @@ def test_binding_covers_header(hip_lib):
 
 
 def test_abi_version_and_error_text(hip_lib):
-    assert hip_lib.sc_abi_version() == 2
+    assert hip_lib.sc_abi_version() == 3
     # argument validation happens before any device work, so it is callable without a GPU
     rc = hip_lib.sc_kmeans_fit(None, 0, 1, 8, 1, None, None, None, 0, 1, 1e-4, None, None, None, None, None, 0, None)
     assert rc == -1
     assert b"null pointer" in hip_lib.sc_last_error()
     assert hip_lib.sc_kmeans_workspace_bytes(400, 576 * 3584, 5) > 0
+
+
+def test_abi_version_matches_header_and_changelog_names_every_symbol_added_since_v2(hip_lib):
+    src = open(os.path.join(ROOT, "include", "streamchat_hip.h")).read()
+    ver = int(re.search(r"#define\s+SC_ABI_VERSION\s+(\d+)", src).group(1))
+    assert hip_lib.sc_abi_version() == ver
+    log = src[src.index("ABI changelog"):src.index("#define SC_ABI_VERSION")]
+    for name in ("sc_kmeans_update", "sc_decode_qkv_f16", "sc_pick_token_f32", "sc_sample_token_f32", "sc_attention_variant"):
+        assert name in log and name in declared_symbols()
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,211 @@
+"""GPU: COMPOSED parity of the C2 chain at a reduced but MERGING geometry (BASELINE.json configs[1], north_star "match
+the reference CPU path on the same frame inputs (identical retrieved-frame indices)").  The SAME 88 seeded uint8 frames and the same
+host RNG draws go through
+
+  HIP   fused preprocess -> ViT-L/14-336 (23 layers) -> mlp2x_gelu (fp16) -> streaming.updating_memory_buffer (chunk 8, K 5, interval 10:
+        11 depth-0 nodes, ONE merge of the first ten = whole-frame k-means over T = 80 frames) -> BERT-large-CLS tree search (HIP encoder,
+        sc_sim_topk)
+  CPU   oracle/torch_ref fp32 encode -> THE SAME host policy functions (updating_memory_buffer / fast_building_memory_tree_summarize_token
+        / fast_search_tree_multi_modal_with_embedding: reference inference_streaming_longva_v2.py:319-358, utiles.py:567-620,715-748)
+        with the k-means, top-k and text-encoder providers swapped for oracle.kmeans_fit (C, fp32 features), oracle.topk and torch_ref's
+        fp32 BERT
+
+and must agree on: the short-memory frame indices, the merge's cluster assignment of all 80 frames and its exit iteration, the tree
+shape and texts, the retrieved nodes (which chunks), hence the retrieved frame indices.  The minimum relative label margin and the
+top-1 / top-2 similarity gaps are printed, so a near-tie (where fp16 feature rounding could legitimately flip a decision) is visible.
+The chunk captioner is a stand-in that names chunks by POSITION (the LLM captioner is outside C2 and would see different bits on the
+two sides); the merge summary is derived from the captions it summarises, as upstream."""
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 88
+MEM = dict(chunk_size=8, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)
+QUESTION = "where did I leave the red cup and what was on the kitchen table"
+
+
+def crossfade_stream(n, seed=1234, period=16, h=336, w=336, noise=6):
+    """uint8 [n, h, w, 3]: frame i cross-fades scene floor(i / period) into the next one (+ small per-frame noise), so the stream walks a
+    continuous path through feature space and the k-means boundaries are decided by real distance comparisons.  (synthetic.frame_stream's
+    hard scene cuts are trivially separable: relative label margin 0.998 on the CPU side; this stream: 0.099 after 9 Lloyd iterations
+    that each move boundary frames - measured with oracle/torch_ref fp32 features when the test was written.)"""
+    scenes = {}
+
+    def scene(s):
+        if s not in scenes:
+            scenes[s] = np.random.default_rng([seed, 0, s]).integers(0, 256, (h, w, 3), dtype=np.uint8).astype(np.float32)
+        return scenes[s]
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        s, a = divmod(i, period)
+        a = a / period
+        d = np.random.default_rng([seed, 1, i]).integers(-noise, noise + 1, (h, w, 3)).astype(np.float32)
+        out[i] = np.clip((1 - a) * scene(s) + a * scene(s + 1) + d, 0, 255).astype(np.uint8)
+    return out
+
+
+class PositionCaptioner:
+    """chunk n (in call order) -> synthetic.caption(n); a summary -> a caption derived from the prompt ids (i.e. from the captions merged)"""
+    config = types.SimpleNamespace(mm_use_im_start_end=False)
+
+    def __init__(self, device):
+        self.device, self.n = device, 0
+
+    def generate_with_image_embedding(self, ids, image_embeddings=None, **kw):
+        if image_embeddings is not None:
+            self.n += 1
+            return torch.tensor([[self.n - 1]])
+        key = torch.as_tensor(ids).reshape(-1).to("cpu", torch.int64).numpy().tobytes()
+        return torch.tensor([[1000 + zlib.crc32(key) % 1000]])
+
+
+def _describe(nodes):
+    def one(n):
+        return dict(depth=n.depth, rows=int(n.centroids.shape[0]), text=n.text, children=[one(c) for c in n.children])
+    return [one(n) for n in nodes]
+
+
+def _frame_index(t, bank0, row_elems):
+    return (t.storage_offset() - bank0.storage_offset()) // row_elems
+
+
+def _run_policy(feats, colbert, tok, record):
+    """the host policy on one feature bank (device or CPU): returns what was decided"""
+    from streamchat_amd import streaming as S, synthetic, utiles as U
+    bank = [feats[i:i + 1] for i in range(feats.shape[0])]
+    cap, stok = PositionCaptioner(feats.device), synthetic.SyntheticTokenizer()
+    torch.manual_seed(0)                                         # init_idx = CPU randperm(T)[:K] inside weighted_kmeans_feature
+    import random
+    random.seed(0)
+    tree, short = S.updating_memory_buffer(bank, None, cap, stok, True, rng=np.random.RandomState(0), **MEM)
+    row = feats[0].numel()
+    short_idx = [int(_frame_index(t, feats, row)) for t in short]
+    path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, QUESTION, feats, colbert, tok, cache=U.CaptionEmbeddingCache())
+    retrieved = []
+    for t in path:                                               # a retrieved node is a run of whole frames of the bank (depth-0 chunk)
+        assert t.shape[0] == MEM["chunk_size"]
+        f0 = int(_frame_index(t, feats, row))
+        retrieved.append(list(range(f0, f0 + t.shape[0])))
+    return dict(tree=_describe(tree), short=short_idx, texts=list(texts), retrieved=retrieved, **record)
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import oracle
+    from oracle import torch_ref as R
+    from streamchat_amd import ops, synthetic, text as T, utiles as U, vision as V
+    dev = torch.device("cuda:0")
+    cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
+    sd_vit = V.random_clip_state_dict(cfg, seed=0, device=dev)
+    sd_proj = V.random_projector_state_dict(1024, 3584, seed=1, device=dev)
+    enc = V.FrameEncoder(V.CLIPVisionTower(sd_vit, cfg, device=dev), V.MMProjector(sd_proj, device=dev), micro_batch=88)
+    u8 = crossfade_stream(N_FRAMES)                                                # 5.5 cross-fades of 16 frames: no trivially separable scene cuts
+    bl = T.BertConfigLite(**T.BERT_LARGE)
+    sd_bert = T.random_bert_state_dict(bl, seed=2, device=dev)
+    tok = T.HashTokenizer()
+
+    # ---- HIP path (the product functions as they are) ----
+    feats = enc.encode_frames_u8(torch.from_numpy(u8).to(dev))                     # [88, 576, 3584] fp16
+    rec_hip = {}
+    real_km = U.weighted_kmeans_feature
+
+    def km_hip(x, k, *a, **kw):
+        red, labels, info = real_km(x, k, *a, return_info=True, **kw)
+        rec_hip.update(labels=labels.cpu().numpy(), exit_iter=int(info["info"][0]), T=int(x.shape[0]))
+        return red, labels
+    U.weighted_kmeans_feature = km_hip
+    try:
+        hip = _run_policy(feats, T.BertEncoder(sd_bert, bl, device=dev), tok, rec_hip)
+    finally:
+        U.weighted_kmeans_feature = real_km
+
+    # ---- CPU path: fp32 encode (oracle/torch_ref), same policy functions, oracle providers ----
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sv = {k: v.float().cpu() for k, v in sd_vit.items()}
+    sp = {k: v.float().cpu() for k, v in sd_proj.items()}
+    with torch.no_grad():
+        ref = torch.cat([R.encode_images(sv, sp, torch.from_numpy(R.preprocess_u8(u8[i:i + 8])), heads=16, patch=14, num_layers=24)
+                         for i in range(0, N_FRAMES, 8)]).contiguous()
+    rec_cpu = {}
+
+    def km_cpu(img_feature, K, weights=None, *, init_idx=None, reseed_idx=None, max_iter=10, **kw):
+        import random
+        Tn, P, D = img_feature.shape
+        if init_idx is None:
+            init_idx = torch.randperm(Tn)[:K]
+        if reseed_idx is None:
+            reseed_idx = [random.randint(0, Tn - 1) for _ in range(max_iter * K)]
+        X = img_feature.reshape(Tn, -1).numpy()
+        o = oracle.kmeans_fit(X, K, np.asarray(init_idx, np.int32), np.asarray(reseed_idx, np.int32), max_iter=max_iter)
+        d2 = np.sort(oracle.kmeans_dist2(X, o["centroids"]), axis=1)
+        rec_cpu.update(labels=o["labels"], exit_iter=o["iters"], T=Tn, margin=(d2[:, 1] - d2[:, 0]) / d2[:, 1])
+        return torch.from_numpy(o["centroids"]).view(K, P, D), torch.from_numpy(o["labels"])
+
+    gaps = []
+
+    def topk_cpu(q, docs, k=1, metric="cos"):
+        idx, sc = oracle.topk(q.numpy(), docs.numpy(), k, metric)
+        s = np.sort(torch.nn.functional.cosine_similarity(q[None], docs).numpy())[::-1]
+        gaps.append(float(s[0] - s[1]) if len(s) > 1 else float("inf"))
+        return torch.from_numpy(idx), torch.from_numpy(sc)
+
+    sdc = {k: v.float().cpu() for k, v in sd_bert.items()}
+
+    class RefBert:
+        def __call__(self, input_ids=None, attention_mask=None, **kw):
+            with torch.no_grad():
+                return types.SimpleNamespace(last_hidden_state=R.bert_last_hidden(sdc, input_ids.cpu(), attention_mask.cpu(), heads=16, layers=24))
+    saved = (U.weighted_kmeans_feature, ops.sim_topk)
+    U.weighted_kmeans_feature, ops.sim_topk = km_cpu, topk_cpu
+    try:
+        cpu = _run_policy(ref, RefBert(), tok, rec_cpu)
+    finally:
+        U.weighted_kmeans_feature, ops.sim_topk = saved
+    return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps)
+
+
+def test_c2_short_memory_frames_identical(c2):
+    assert c2["hip"]["short"] == c2["cpu"]["short"] and len(c2["hip"]["short"]) == 5
+    assert all(N_FRAMES - 20 <= f < N_FRAMES for f in c2["hip"]["short"])
+
+
+def test_c2_merge_cluster_assignments_identical(c2):
+    h, c = c2["hip"], c2["cpu"]
+    m = c["margin"]
+    print(f"\n[C2] merge k-means T={c['T']} K={MEM['num_clusters']}: oracle exit iteration {c['exit_iter']}, HIP {h['exit_iter']}; min relative label margin "
+          f"{m.min():.3e} (row {int(m.argmin())}); cluster sizes {np.bincount(c['labels'], minlength=5).tolist()}")
+    assert h["T"] == c["T"] == 80
+    assert np.array_equal(h["labels"], c["labels"]), "merge cluster assignments differ between the HIP path and the CPU reference path"
+    assert h["exit_iter"] == c["exit_iter"]
+    assert c["exit_iter"] >= 3 and m.min() < 0.5          # the stream is NOT trivially separable: boundaries moved over several Lloyd iterations
+
+
+def test_c2_tree_and_retrieved_frames_identical(c2):
+    h, c = c2["hip"], c2["cpu"]
+    print(f"\n[C2] tree: {[(n['depth'], n['rows'], len(n['children'])) for n in c['tree']]}; retrieved chunks (first frame) "
+          f"{[r[0] for r in c['retrieved']]}; top-1 minus top-2 cosine per search level (fp32 side): {['%.3e' % g for g in c2['gaps']]}")
+    assert h["tree"] == c["tree"]                                 # depths, row counts, texts, children - the whole shape
+    assert [n["depth"] for n in c["tree"]] == [1, 0] and c["tree"][0]["rows"] == 5 and len(c["tree"][0]["children"]) == 10
+    assert h["texts"] == c["texts"]
+    assert h["retrieved"] == c["retrieved"]                       # identical retrieved-frame indices
+    assert len(c["retrieved"]) == 2 and c["retrieved"][1][0] == 80      # the best child of the merged node + the one redundant depth-0 node
+
+
+def test_c2_merged_centroids_close(c2):
+    """the merged node's 5 centroid frames: HIP (fp16 features, fp32 means) vs CPU (fp32 features): same clusters, feature rounding apart"""
+    from _tol import assert_close_fp16
+    hip_feats, ref = c2["feats"].float().cpu(), c2["ref"]
+    labels = c2["cpu"]["labels"]
+    for k in range(5):
+        rows = np.nonzero(labels == k)[0]
+        assert_close_fp16(hip_feats[rows].mean(0), ref[rows].mean(0), max_rel=6e-3, what=f"centroid {k} ({len(rows)} frames)")

@@ -381,6 +381,8 @@ def test_resolve_sampling_follows_hf_generation_config_semantics():
     assert R(qwen, True, 0.2, None) == S(0.2, 20, 1.0, 1.05)
     assert R(qwen, True) == S(0.7, 20, 0.8, 1.05)
     assert R(qwen, False) == S(0.0, 0, 1.0, 1.05)
+    assert R(qwen, LM._UNSET) == S(0.7, 20, 0.8, 1.05)            # do_sample not passed: the checkpoint's file decides ...
+    assert R({}, LM._UNSET) == R({}, None) == S(0.0, 0, 1.0, 1.0)  # ... then HF's default: greedy
     assert R(qwen, True, 0.2, None, top_k=None, repetition_penalty=None) == S(0.2, 0, 1.0, 1.0)
     with pytest.raises(NotImplementedError):
         R({}, True, 0.2, 0.9, top_k=None)                                                   # nucleus without top-k

@@ -81,6 +81,44 @@ def test_c5_multi_round_session_equals_single_stream_functions():
     assert len(mine) == 3 and all(torch.equal(a, b) for a, b in zip(mine, ref))
 
 
+def test_c5_session_decodes_inside_every_round():
+    """C5 as configured (BASELINE.json configs[4]: "multi-round 7B decode"): `session(decode_tokens=8)` prefills and then decodes 8 tokens
+    with the replayed hipGraph in EVERY round (the graph is captured once and must survive the next round's prefill, which rewinds and
+    re-fills the same KV cache).  Checked against the same model driven round by round through `generate_with_image_embedding`
+    (prefill + the eager token loop) on the feature block the session retrieved.  A 2-layer Qwen2-7B-width model keeps it short."""
+    import bench
+    from streamchat_amd import llm as LM
+    dev = torch.device("cuda:0")
+    pipe = bench.Pipeline(dev, 0, with_llm=False)
+    qc = LM.Qwen2ConfigLite(**dict(LM.QWEN2_7B, layers=2))
+    pipe.model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(LM.random_qwen2_state_dict(qc, seed=4, device=dev), qc, device=dev, max_seq=4 * 23040 + 8192), pipe.enc)
+    pipe.prepare_rounds(2, 440)
+    got = pipe.session(decode_tokens=8)
+    assert [len(r["tokens"]) for r in got["rounds"]] == [8, 8]
+    contexts = [r["context"] for r in got["rounds"]]
+    assert contexts[0] > 5 * 576 + 2 * 40 * 576 - 1 and contexts[1] >= contexts[0]
+    # the same rounds again: prefill through the public generate call on the rows the session's Refs describe, then the EAGER one-token
+    # forward teacher-forced with the session's tokens: every token the graph emitted must be the eager arg-max (up to an fp16-level
+    # tie: the two loops split the KV range differently, so their logits differ in the last bits)
+    from streamchat_amd import sharded as SH
+    mem = got["mem"]
+    for r, rec in enumerate(got["rounds"]):
+        rows = []
+        for piece in rec["wanted"]:
+            for kind, i, f in piece:
+                rows.append(pipe.round_feats[i][f] if kind == "frame" else mem.store[(SH.MERGE, i)][f])
+        emb = torch.stack(rows).reshape(-1, 3584)
+        pipe.question = pipe.questions[r]
+        pipe.prefill(emb, rec["path_text"][-1])
+        assert pipe.last["context"] == rec["context"]
+        lm = pipe.model.lm
+        tok = int(pipe.last["first_token"][0, 0])
+        for t in rec["tokens"]:
+            logits = lm.forward(lm.embed_tokens(torch.tensor([tok], device=dev))).float()
+            assert float(logits[t]) >= float(logits.max()) - 2e-3 * float(logits.abs().max()), (r, t, int(logits.argmax()))
+            tok = t
+
+
 def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
     """A 1-rank RCCL ("nccl") process group on the GPU box: the sharded step with `always_collective` makes exactly the calls an
     N-rank run makes (all_gather_object of captions, broadcast_object_list of the summary, the int64 Ref broadcast,
@@ -115,30 +153,75 @@ def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
         dist.destroy_process_group()
 
 
-def _bench_json(args, env, nproc=1):
+def _bench_json(args, env, nproc=1, launcher="torchrun"):
+    """bench.py as a subprocess: under torch.distributed.run like the driver launches N > 1 (launcher="torchrun"), or as the bare command
+    `python bench.py --gpus N ...` (launcher="bare": bench.py must start its ranks itself)."""
     import json
     import subprocess
     cmd = [sys.executable]
-    if nproc > 1:
+    if nproc > 1 and launcher == "torchrun":
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29533"]
     cmd += [os.path.join(ROOT, "bench.py")] + args
-    r = subprocess.run(cmd, env={**os.environ, **env}, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, env={**base, **env}, cwd=ROOT, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
-def test_processes_through_torchrun_retrieve_and_prefill_like_one(nproc):
-    """The whole `bench.py --gpus N` job (N = 2, 4) as the driver launches it (torch.distributed.run, one process per rank, real HIP kernels in both,
-    7B prefill on rank 0), on this 1-GPU box: both ranks share device 0 (SC_ALL_RANKS_ON_GPU0) and the collectives go through gloo with
-    host staging (SC_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  The 880-frame stream straddles the ranks inside its
-    merge group (frames 0..399 over ranks owning [0, 440) and [440, 880) at N = 2; three ranks at N = 4), so the P2P fetch, the all-gather of the selected rows, the
-    Ref broadcast and the caption exchange all carry data.  Retrieved frames, path text and the first generated token must equal the
-    1-process run of the same stream."""
-    common = ["--config", "C4", "--frames", "880", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
-    one = _bench_json(common + ["--force-sharded"], {})
-    two = _bench_json(common + ["--gpus", str(nproc)], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=nproc)
-    assert two["n_gpus"] == nproc and one["n_gpus"] == 1
+C4_SMALL = ["--config", "C4", "--frames", "880", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
+_one_process = {}
+
+
+def _c4_small_one_process():
+    if not _one_process:
+        _one_process.update(_bench_json(C4_SMALL + ["--force-sharded"], {}))
+    return _one_process
+
+
+@pytest.mark.parametrize("nproc,launcher", [(2, "bare"), (4, "torchrun")])
+def test_processes_retrieve_and_prefill_like_one(nproc, launcher):
+    """The whole `bench.py --gpus N` job (7B prefill on rank 0, real HIP kernels in every rank) on this 1-GPU box: all ranks share device 0
+    (SC_ALL_RANKS_ON_GPU0) and the collectives go through gloo with host staging (SC_DIST_BACKEND=gloo; RCCL refuses two ranks on one
+    device).  N = 2 is started as the BARE command `python bench.py --gpus 2 ...` — no launcher around it: bench.py has to start its
+    ranks itself — N = 4 through torch.distributed.run as the task brief's driver does.  The 880-frame stream
+    straddles the ranks inside its merge group (frames 0..399 over ranks owning [0, 440) and [440, 880) at N = 2; three ranks at N = 4),
+    so the P2P fetch, the all-gather of the selected rows, the Ref broadcast and the caption exchange all carry data.  Retrieved frames,
+    path text and the first generated token must equal the 1-process run of the same stream, and the record must say what it is."""
+    one = _c4_small_one_process()
+    many = _bench_json(C4_SMALL + ["--gpus", str(nproc)], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=nproc, launcher=launcher)
+    assert many["n_gpus"] == nproc and one["n_gpus"] == 1
+    for k in ("retrieval_crc32", "first_token", "context_tokens"):
+        assert one["config"][k] == many["config"][k], (k, one["config"][k], many["config"][k])
+    assert many["config"]["launcher"] == ("self (bare command)" if launcher == "bare" else "torch.distributed.run")
+    assert "880-frame" in many["metric"] and many["config"]["frames_total"] == 880
+    assert many["encode_frames_per_s"] > 0 and many["encode_frames_per_s_1gpu_same_job"] > 0 and "SERIAL on rank 0" in many["scaling_note"]
+    keys = list(many)
+    assert keys.index("encode_frames_per_s") < keys.index("config")       # the encode rate leads the record
+
+
+def test_weak_scaling_record_names_the_total_frames():
+    """Default workload (C3 per GPU) at N = 2: the metric string must name the frames the job processed in total, not "1024-frame"."""
+    rec = _bench_json(["--gpus", "2", "--frames", "440", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0", "--no-llm"],
+                      {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=2, launcher="bare")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["frames_total"] == 880 and rec["config"]["frames_per_gpu"] == 440
+    assert "880-frame stream in total = 440 frames per GPU x 2 GPUs" in rec["metric"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
+def test_two_ranks_on_two_gpus_over_rccl_equal_one_process():
+    """On the first box with more than one GPU: the same 880-frame job on REAL RCCL (batch_isend_irecv of the straddling merge group,
+    all_gather_into_tensor of the selected rows, the Ref broadcast over xGMI), started as the bare command."""
+    one = _c4_small_one_process()
+    two = _bench_json(C4_SMALL + ["--gpus", "2"], {}, nproc=2, launcher="bare")
+    assert two["n_gpus"] == 2
     for k in ("retrieval_crc32", "first_token", "context_tokens"):
         assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
+
+
+def test_bare_command_refuses_more_ranks_than_gpus():
+    """`--gpus 64` on a box without 64 GPUs (and without the shared-device test switch) must fail loudly before anything is launched."""
+    import subprocess
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SC_ALL_RANKS_ON_GPU0")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=base, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "exposes" in r.stderr

@@ -26,8 +26,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+DUPLICATES = False                       # scenario switch (set per worker): frames that are exact copies -> empty clusters -> reseeds
+
+
 def _segment(seg, n):
     g = torch.Generator().manual_seed(1000 + seg)
+    if DUPLICATES:      # two distinct frame values per segment, the rare one on every 5th frame: two init rows are usually the SAME
+                        # value, the second cluster comes up empty and is re-seeded from `reseed_idx` (utiles.py:312-313)
+        v = torch.where(torch.arange(n) % 5 == 4, 7.0, 0.0).view(n, 1, 1) + 100.0 * seg
+        return (v + torch.zeros(n, P_, D_)).contiguous()
     base = torch.arange(n, dtype=torch.float32).view(n, 1, 1) // MEM["chunk_size"] * 3.0 + 100.0 * seg
     return (base + 0.05 * torch.randn(n, P_, D_, generator=g)).contiguous()
 
@@ -64,15 +71,23 @@ class EmbModel:                               # CLS embedding = seeded pseudo-ra
         return types.SimpleNamespace(last_hidden_state=out)
 
 
+RESEEDS = []                             # per k-means call of this process: number of passes with an empty cluster
+
+
 def _patch_providers():
     import oracle
     from streamchat_amd import ops, utiles as U
 
-    def kmeans_feature(img_feature, K, weights=None, *, init_idx=None, **kw):
+    def kmeans_feature(img_feature, K, weights=None, *, init_idx=None, reseed_idx=None, max_iter=10, **kw):
+        import random
         T, P, D = img_feature.shape
         if init_idx is None:
             init_idx = torch.randperm(T)[:K]
-        r = oracle.kmeans_fit(img_feature.reshape(T, -1).numpy(), K, np.asarray(init_idx, np.int32), np.zeros(10 * K, np.int32))
+        if reseed_idx is None:              # the product's default (utiles.weighted_kmeans_feature): Python's GLOBAL `random`, advanced
+            reseed_idx = [random.randint(0, T - 1) for _ in range(max_iter * K)]
+        r = oracle.kmeans_fit(img_feature.reshape(T, -1).numpy(), K, np.asarray(init_idx, np.int32), np.asarray(reseed_idx, np.int32),
+                              max_iter=max_iter, trace=True)
+        RESEEDS.append(int(sum(len(set(t.tolist())) < K for t in r["trace"])))      # assignment passes that left a cluster empty
         return torch.from_numpy(r["centroids"]).view(K, P, D), torch.from_numpy(r["labels"])
 
     def sim_topk(q, docs, k=1, metric="cos"):
@@ -90,8 +105,10 @@ def _describe(nodes):
 
 def _single_stream():
     """the reference policy through the single-GPU functions: per update (tree description, short rows, path rows, path texts)"""
+    import random
     from streamchat_amd import streaming as S, utiles as U
     torch.manual_seed(7)
+    random.seed(5)
     rng = np.random.RandomState(11)
     tree, out = None, []
     for seg, n in enumerate(SEGMENTS):
@@ -105,8 +122,10 @@ def _single_stream():
 
 
 def _sharded(ctx):
+    import random
     from streamchat_amd import sharded as SH, utiles as U
     torch.manual_seed(7)
+    random.seed(5)
     rng = np.random.RandomState(11)
     mem = SH.ShardedMemory(ctx, **MEM)
     out = []
@@ -128,15 +147,25 @@ def _sharded(ctx):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, duplicates=False):
     try:
+        global DUPLICATES
+        DUPLICATES = duplicates
         os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         from streamchat_amd import dist as D
         _patch_providers()
         ctx = D.init_from_env("cpu")
+        import random
         ref = _single_stream()
+        n_reseed_ref = sum(RESEEDS)
+        probe_ref = (random.random(), float(torch.rand(1)))
         got = _sharded(ctx)
+        probe = (random.random(), float(torch.rand(1)))
         ok, why = True, ""
+        if probe != probe_ref:        # Python's `random` and the CPU torch generator end where the single-stream run leaves them, on EVERY rank
+            ok, why = False, f"host RNG streams left the single-stream position: {probe} != {probe_ref}"
+        if duplicates and n_reseed_ref == 0:
+            ok, why = False, "the duplicate-frame stream met no empty cluster: the scenario does not test the reseed path"
         for u, (r, g) in enumerate(zip(ref, got)):
             if r["tree"] != g["tree"]:
                 ok, why = False, f"update {u}: tree differs"
@@ -154,11 +183,11 @@ def _worker(rank, world, port, q):
         raise
 
 
-def _run_world(world):
+def _run_world(world, duplicates=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, duplicates)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=300) for _ in ps)
     [p.join(timeout=60) for p in ps]
@@ -173,6 +202,14 @@ def test_sharded_equals_single_stream_world2_and_world4():
     w2 = _run_world(2)
     w4 = _run_world(4)
     assert w2 == w4                                          # identical retrieved (segment, frame) indices for P = 2 and P = 4
+
+
+@pytest.mark.timeout(600)
+def test_sharded_empty_cluster_reseeds_stay_in_lockstep_with_single_stream():
+    """ADVICE r02 (sharded.py): a stream of duplicate frames makes merge k-means calls come up with an empty cluster, whose reseed
+    rows come from Python's global `random` (utiles.py:312-313).  Every rank must draw them (the executor changes from merge to
+    merge), otherwise the ranks drift apart and the merge centroids differ from the single-stream run after the first merge."""
+    _run_world(3, duplicates=True)
 
 
 def test_world1_sharded_memory_is_views_and_equal():
