@@ -126,7 +126,8 @@ class Pipeline:
         ids = tokenizer_image_token(conv.get_prompt(), self.llm_tok, -200, return_tensors="pt").unsqueeze(0)
         out = self.model.generate_with_image_embedding(ids, image_embeddings=[image_embeddings], modalities=["video"], do_sample=False,
                                                        max_new_tokens=1)
-        self.last.update(first_token=out, context=int(image_embeddings.shape[0]) + ids.shape[1] - 1)
+        rows = sum(int(t.shape[0]) for t in image_embeddings) if isinstance(image_embeddings, (list, tuple)) else int(image_embeddings.shape[0])
+        self.last.update(first_token=out, context=rows + ids.shape[1] - 1)
 
     def step(self):
         """single GPU, through the reference-seam functions (streaming.updating_memory_buffer, utiles.fast_search_tree_...)"""
@@ -147,10 +148,8 @@ class Pipeline:
         path_feats, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, short_emb, self.colbert, self.tok,
                                                                               cache=U.CaptionEmbeddingCache())
         self.last = dict(tree=tree, short=short, related=related, path_text=path_text, path_feats=path_feats)
-        if self.model is not None:
-            long_emb = torch.cat([t.reshape(-1, t.shape[-1]) for t in path_feats], dim=0)
-            self.last["image_embeddings"] = image_embeddings = torch.cat([short_emb, long_emb], dim=0)
-            self.prefill(image_embeddings, path_text[-1])
+        if self.model is not None:       # [short | retrieved] pieces go straight into the spliced prompt (no torch.cat of the 350 MB block)
+            self.prefill([short_emb] + [t.reshape(-1, t.shape[-1]) for t in path_feats], path_text[-1])
         return self.last
 
     def step_sharded(self):
@@ -249,7 +248,8 @@ class Pipeline:
 def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     """SURVEY §8(d), to the letter: the CPU restatement of the reference path (oracle/torch_ref.py: plain fp32 PyTorch — the arithmetic
     the reference's CPU path runs) timed on THIS box's host cores next to the GPU number, on a bounded sample:
-      * thread sweep on a BATCH of 16 frames (32 / 64 / 128 / all cores; the best count is used for everything below);
+      * thread sweep on a BATCH of 4 frames (32 / 64 / 128 / all cores, ascending, stopped once a count is > 30 % slower than the best:
+        oversubscribed runs take minutes); the best count is used for everything below;
       * ViT-L + projector on a 64-frame slice of the stream (`n_cpu_frames`, = C1's whole encode);
       * C1 in full, once: that encode + the reference's [T,K,D]-broadcast k-means (utiles.py:294-318 formula) on its 64 x 2 064 384
         features, K = 8, run to its own exit;
@@ -270,11 +270,13 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     with torch.no_grad():
         torch.set_num_threads(min(32, cores))
         R.encode_images(sd, sp, x[:2], heads=16, patch=14, num_layers=24)                  # warm-up (thread pool, allocator, page-in)
-        for th in sorted({t for t in (32, 64, 128, cores) if t <= cores} or {cores}):
+        for th in sorted({t for t in (32, 64, 128, cores) if t <= cores} or {cores}):     # ascending; stops once more threads clearly lose
             torch.set_num_threads(th)
             t0 = time.time()
-            enc(x[:16])
-            sweep[th] = round((time.time() - t0) / min(16, n_cpu_frames), 4)
+            enc(x[:4])
+            sweep[th] = round((time.time() - t0) / min(4, n_cpu_frames), 4)
+            if sweep[th] > 1.3 * min(sweep.values()):
+                break
         threads = min(sweep, key=sweep.get)
         torch.set_num_threads(threads)
         t0 = time.time()
@@ -340,7 +342,7 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     return dict(value=round(n_frames / total, 5), unit="frames/s", cores=threads, cores_present=cores, kind="port", c1_frames_per_s=round(c1, 4),
                 thread_sweep_s_per_frame=sweep, host_seconds=round(host_s, 1),
                 sample=f"oracle/torch_ref ViT-L+projector fp32 on a {n_cpu_frames}-frame slice in batches of 16 ({t_frame:.3f} s/frame at {threads} threads = "
-                       f"best of the sweep {sweep} on a 16-frame batch; {cores} cores present) x{n_frames}; C1 RUN IN FULL: those {n_cpu_frames} frames + "
+                       f"best of the sweep {sweep} on a 4-frame batch; {cores} cores present) x{n_frames}; C1 RUN IN FULL: those {n_cpu_frames} frames + "
                        f"reference-formula k-means K=8 on their features to its exit ({it8 + 1} iterations, {t_km_c1:.1f} s) = {c1:.3f} frames/s; merge k-means: "
                        f"{km_note} x {km_iters_gpu} Lloyd passes (the GPU run's count)" + note + "; retrieval negligible")
 
@@ -610,7 +612,7 @@ def main():
         gb_tok = 14.1 + 2 * 28 * 4 * 128 * ctxlen * 2 / 1e9       # fp16 weights incl. lm_head + KV bytes per token
         out["decode_tokens_per_s"] = round(rate, 2)
         out["decode_tokens"] = a.decode_tokens
-        out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv + split-KV k_attn (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
+        out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv / k_decode_qkv + k_attn_decode (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
                                                 unit="GB/s", frac=round(rate * gb_tok / HBM_PEAK_GBS, 4), gb_per_token=round(gb_tok, 2))
     if not a.no_cpu_baseline and world == 1 and config in ("C2", "C3"):
         out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames, max((i[0] + 1 for i in km_infos[-1:]), default=3))

@@ -42,6 +42,8 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *      + sc_pick_token_f32, sc_pick_token_workspace_bytes     (arg-max / temperature sampling on device)
  *      + sc_sample_token_f32, sc_sample_token_workspace_bytes (repetition penalty / top-k / top-p chain)
  *      + sc_attention_variant      (which attention kernel a shape is dispatched to)
+ *      round 3: + sc_gemm_headed_f16 (rotary / column-scale GEMM epilogues), sc_rope_table_f32, sc_rope_f32in_f16, sc_decode_qkv_tab_f16;
+ *               sc_attention_f16's `causal` argument became a flag word (bit 1 = SC_ATTN_Q_PRESCALED; 0 / 1 mean what they meant)
  *      (these seven shipped in round 2 under version 2 by mistake; 3 is the first version that guarantees them)
  */
 #define SC_ABI_VERSION 3
@@ -131,7 +133,7 @@ int sc_sim_topk(const float* q, const float* docs, int M, int d, int k, int metr
  * longva/model/multimodal_encoder/clip_encoder.py:76, multimodal_projector/builder.py:41-48,
  * utiles.py:707,728 and longva/model/language_model/llava_qwen.py:155.
  */
-enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2, SC_EPI_SWIGLU = 3 };
+enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2, SC_EPI_SWIGLU = 3, SC_EPI_ROPE = 4, SC_EPI_COLSCALE = 5 };
 /* SC_EPI_SWIGLU: W rows are interleaved per 4 output columns as (gate_j, gate_j+1, up_j, up_j+1); the kernel writes
  * silu(gate) * up to C[M, N/2] (Qwen2MLP act_fn(gate_proj(x)) * up_proj(x) without the [M, 2I] intermediate). */
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N]).  fp16 in, fp32 accumulate (MFMA),
@@ -144,6 +146,17 @@ enum { SC_EPI_NONE = 0, SC_EPI_QUICK_GELU = 1, SC_EPI_GELU_ERF = 2, SC_EPI_SWIGL
 int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const void* residual, int ldr,
                 void* C, int ldc, int M, int N, int K, int epilogue, int out_f32, int a_grp,
                 int a_grp_stride, int a_grp_off, sc_stream_t stream);
+
+/* The same GEMM with an epilogue that knows the output columns are HEADS of width 128 (round 3, ABI 3; served by the hand-scheduled
+ * 256 x 256 kernel only: N % 256 == 0, K % 128 == 0, lda % 8 == 0, ldc % 8 == 0, 16-byte aligned A / W / C / bias - otherwise
+ * SC_ERR_UNSUPPORTED and the caller takes sc_gemm_f16(out_f32 = 1) + sc_rope_f32in_f16, which produce the same numbers):
+ *   mode SC_EPI_ROPE      Qwen2 q / k|v projections (HF Qwen2Attention behind reference llava_qwen.py:155): columns [0, lead_cols) are
+ *                         rotary heads - rotate-half RoPE of the fp32 sum (acc + bias) with row pos0 + m of `rope_tab`
+ *                         (sc_rope_table_f32), rounded to fp16 ONCE; columns >= lead_cols (the V part) get the bias only.
+ *   mode SC_EPI_COLSCALE  (acc + bias) * col_scale for columns < lead_cols, plain beyond: the q third of CLIP's fused q|k|v projection
+ *                         leaves pre-scaled for SC_ATTN_Q_PRESCALED (HF CLIPAttention scales q the same way: clip_encoder.py:76). */
+int sc_gemm_headed_f16(const void* A, int lda, const void* W, const void* bias, void* C, int ldc, int M, int N, int K,
+                       int mode, const float* rope_tab, int pos0, int lead_cols, float col_scale, sc_stream_t stream);
 /* ViT token assembly + pre-LayerNorm (HF CLIPVisionEmbeddings + pre_layrnorm):
  *   out[n, 0]     = LN(cls + pos[0]);  out[n, 1 + p] = LN(patch[n*P + p] + pos[1 + p])
  * patch [N*P, D], cls [D], pos [P+1, D], out [N*(P+1), D], all fp16; D % 8 == 0, D <= 4096. */
@@ -178,6 +191,17 @@ int sc_rope_row_f16(void* buf, int ld, const int32_t* row_index, int heads, int 
  * ([rows, ld] buffer, K = the first kv_heads*Dh columns) in one launch. */
 int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, const int32_t* row_index, int kv_heads, int Dh,
                        float theta, sc_stream_t stream);
+/* Rotary embedding from fp32 projections with ONE rounding (round 3, ABI 3).  sc_rope_table_f32: tab[pos][0][j] = cos(pos * theta^(-2j/Dh))
+ * * scale, tab[pos][1][j] = sin(..) * scale, j < Dh/2, pos < max_pos (fp32; scale = softmax scale * log2 e for the QUERY table, 1 for keys).
+ * sc_rope_f32in_f16: x [rows, ldx] fp32 (projection + bias) -> out [rows, ldo] fp16: the first `heads` heads of width Dh rotated with the
+ * table row positions[r] (or pos0 + r), `plain_cols` further columns cast unchanged (the V part of a k|v projection).
+ * sc_decode_qkv_tab_f16: sc_decode_qkv_f16 with this arithmetic (tab_q scaled, tab_k not): q leaves pre-scaled for SC_ATTN_Q_PRESCALED. */
+int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, float scale, sc_stream_t stream);
+int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, const int32_t* positions, int pos0, int rows, int heads, int Dh,
+                      int plain_cols, void* out, int ldo, sc_stream_t stream);
+int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma,
+                          float rms_eps, void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh,
+                          int K, const float* tab_q, const float* tab_k, sc_stream_t stream);
 /* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
  * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
  *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)
@@ -197,7 +221,10 @@ int sc_avgpool_tokens_f16(const void* in, void* out, int B, int P, int D, int r,
  *   q   [B, Sq,  Hq,  Dh]  row stride ldq elements, head h at column h*Dh
  *   k,v [B, Skv, Hkv, Dh]  row strides ldk / ldv (GQA: Hq % Hkv == 0)
  *   out [B, Sq,  Hq,  Dh]  row stride ldo
- *   causal: 0 = full; 1 = causal with the Sq queries aligned to the END of the Skv keys
+ *   causal: bit 0: 0 = full, 1 = causal with the Sq queries aligned to the END of the Skv keys;
+ *           bit 1 (SC_ATTN_Q_PRESCALED, ABI 3): q already carries scale * log2(e) - applied by its producer to the fp32 projection before
+ *           the one rounding to fp16 (sc_gemm_headed_f16, sc_decode_qkv_tab_f16, sc_rope_f32in_f16 with a scaled table) - and `scale` is
+ *           ignored: the kernel takes p = 2^(q.k - m) without a per-score multiply
  *   kv_len: optional [B] int32 valid key count per batch row (padding mask) or NULL.  Dh in {32, 64, 128}.
  *   nsplit > 1: split-KV ("flash-decoding") for few queries over a long cache — the key range is cut into nsplit slices
  *   processed by separate workgroups and merged; needs ws of B*Hq*Sq*nsplit*(Dh+2)*4 bytes.  nsplit = 1: ws may be NULL.
@@ -207,14 +234,16 @@ int sc_avgpool_tokens_f16(const void* in, void* out, int B, int P, int D, int r,
  *   q_batch_stride / o_batch_stride (elements; 0 = Sq*ldq / Sq*ldo): distance between consecutive batch rows of q / out, so the
  *   head-packed addressing also works for B > 1 (batched decode: q is [B, Hq*Dh] and its batch stride is Hq*Dh, not G*Dh).
  *   k / v batch rows are Skv*ldk / Skv*ldv apart. */
+enum { SC_ATTN_CAUSAL = 1, SC_ATTN_Q_PRESCALED = 2 };
 int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                      int ldo, int B, int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal,
                      const int32_t* kv_len, int nsplit, void* ws, size_t ws_bytes, int q_head_stride,
                      int o_head_stride, int64_t q_batch_stride, int64_t o_batch_stride, sc_stream_t stream);
 
 /* Which kernel sc_attention_f16 dispatches for a shape in this process: 0 = k_attn (32 queries per wave, whole 64-row tiles), 1 = k_attn
- * long-prefill variant (Dh = 128, Sq >= 2048, no split-KV: 48 queries per wave, half tiles), 2 = k_attn_fat (the same shapes with
- * SC_ATTN_FAT=1 in the environment: hand-scheduled v_mfma_f32_32x32x16_f16 loop, one wave per SIMD).  Host-only query for tests and
+ * long-prefill variant (Dh = 128, Sq >= 2048, no split-KV: 48 queries per wave, half tiles), (2 = round 2's hand-scheduled k_attn_fat:
+ * removed in round 3), 3 = k_attn_decode (Dh = 128, at most
+ * 16 query rows, split-KV, non-causal = a decode step: every wave streams its own run of 32-row chunks).  Host-only query for tests and
  * profiles; the arithmetic contract of sc_attention_f16 does not depend on it. */
 int sc_attention_variant(int Dh, int Sq, int nsplit);
 

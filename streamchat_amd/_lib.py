@@ -44,6 +44,11 @@ SIGNATURES = {
     "sc_pool_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_avgpool_tokens_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sc_gemm_headed_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "sc_rope_table_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "sc_rope_f32in_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sc_decode_qkv_tab_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_void_p, c_void_p]),
     "sc_rope_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "sc_rope_qk_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_rope_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),

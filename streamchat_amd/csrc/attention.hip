@@ -39,7 +39,13 @@ __device__ __forceinline__ void lds_load16(const void* base, int extent, char* l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int DH, int QB, bool CAUSAL, int CH>
+// PRE (SC_ATTN_Q_PRESCALED): the caller's Q already carries the softmax scale in the log2 domain (q * scale * log2 e, applied by the
+// PRODUCER of q to its fp32 accumulators before the one rounding to fp16: the rotary / column-scale epilogues of gemm.hip, k_decode_qkv,
+// k_rope_f32in).  In the steady-state loop the softmax reference then enters through the C operand of the first S MFMA of a k-step
+// chain (accumulators start at -m instead of 0): the scores leave the matrix pipe as s - m and p = 2^that needs no FMA - one VALU
+// instruction less per score in an issue-bound loop (+4 % at 49 k tokens, +3 % on the ViT shape, profiles/r03_run2_attn_prescale_ab.md).
+// Scaling an fp16 q inside this kernel instead (a second rounding) was measured and rejected: error x2-7 on peaky rows.
+template <int DH, int QB, bool CAUSAL, int CH, bool PRE>
 __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                               const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
                                               int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
@@ -89,7 +95,9 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         qr = qr < Sq ? qr : Sq - 1;
         const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+        for (int ds = 0; ds < DS; ++ds) {
+            qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+        }
     }
 
     // ---- staging sources ----
@@ -206,7 +214,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     constexpr int NCH = KVT / CH, KVB = CH / 16, PC = CH / 32;
     // nkvb: the first nkvb 16-row blocks of the chunk hold a key this wave can see (KVB in the steady state: folds away); the MFMAs,
     // exponentials and P.V k-steps of the other blocks are skipped (ragged last tile: 577 = 9 x 64 + 1 keys per ViT frame; causal diagonal)
-    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB], int nkvb) {
+    sc_f4 negm[QB];                               // PRE, steady state: (-m, -m, -m, -m) of every q-block = the C operand the score chains start from
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) negm[qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB], int nkvb, auto steady) {
         constexpr int NKF = KVB * DS;
         const char* skc = sk + c * KVB * KBLK;
         sc_h8 kfr[2];
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
             if (i + 1 < NKF) kfr[(i + 1) & 1] = *reinterpret_cast<const sc_h8*>(skc + ((i + 1) / DS) * KBLK + k_off[(i + 1) % DS]);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const sc_f4 acc = ds == 0 ? sc_f4{0.f, 0.f, 0.f, 0.f} : s[kvb][qb];
+                const sc_f4 acc = ds == 0 ? ((PRE && decltype(steady)::value) ? negm[qb] : sc_f4{0.f, 0.f, 0.f, 0.f}) : s[kvb][qb];
                 if (kvb < nkvb) s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[i & 1], qf[qb][ds], acc, 0, 0, 0);
                 else s[kvb][qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
             }
@@ -234,14 +245,15 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
         const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
         const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) * scale_log2;      // scale > 0: max commutes with scaling
+        return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) * (PRE ? 1.0f : scale_log2);      // scale > 0: max commutes with scaling
     };
     // P = 2^(s*scale - m) -> fp16 MFMA operand + row sums (one packed FMA per pair of scores)
     // scalar fp32 math on purpose (the file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (and
     // v_dot2_f32_f16) do not execute under an MFMA of the same SIMD - each costs ~11 cycles of the matrix pipe, while up to four
     // plain v_fma_f32 / v_add_f32 per MFMA are free (tools/probes/probe_fat.hip, profiles/r02_run30_probe_fat.log)
-    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC], int nkvb) {
+    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC], int nkvb, auto steady) {
         const float nm = -m_sub;
+        constexpr bool DIRECT = PRE && decltype(steady)::value;       // the reference is already inside s
         float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kvb = 0; kvb < KVB; ++kvb)
@@ -249,8 +261,8 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
             for (int r = 0; r < 4; r += 2) {
                 float p0 = 0.f, p1 = 0.f;
                 if (kvb < nkvb) {
-                    p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r], scale_log2, nm));
-                    p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm));
+                    p0 = __builtin_amdgcn_exp2f(DIRECT ? s[kvb][qb][r] : (PRE ? s[kvb][qb][r] + nm : __builtin_fmaf(s[kvb][qb][r], scale_log2, nm)));
+                    p1 = __builtin_amdgcn_exp2f(DIRECT ? s[kvb][qb][r + 1] : (PRE ? s[kvb][qb][r + 1] + nm : __builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm)));
                 }
                 if (!LSUM_MFMA) { ps0 += p0; ps1 += p1; }
                 pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p0;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                     if (CAUSAL) nkvb = min(nkvb, ((qw_last + coff - (t * KVT + c * CH)) >> 4) + 1);      // ... that the wave's last query still sees
                     nkvb = max(0, min(nkvb, KVB));
                     sc_f4 s[KVB][QB];
-                    s_part(sk, c, s, nkvb);
+                    s_part(sk, c, s, nkvb, std::false_type{});
                     sc_h8 pf[QB][PC];
                     const int kv_t0 = t * KVT + c * CH + g * 4;
 #pragma unroll
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
                         if (LSUM_MFMA) ol[qb] *= alpha;
 #pragma unroll
                         for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
-                        p_part(s, qb, m_use, pf, nkvb);
+                        p_part(s, qb, m_use, pf, nkvb, std::false_type{});
                     }
                     pv_part(sk + TILE, c, pf, nkvb);
                 }
@@ -337,6 +349,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) ok = ok && (m_run[qb] > -INFINITY);
             if (!__all(ok)) continue;                                                 // a row without any visible key yet
+            if (PRE) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) negm[qb] = sc_f4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
+            }
             while (t < t_hi && !masked(t)) {
                 const int cur = (t - t_lo) & 1;
                 if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
@@ -344,10 +360,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     sc_f4 s[KVB][QB];
-                    s_part(sk, c, s, KVB);
+                    s_part(sk, c, s, KVB, std::true_type{});
                     sc_h8 pf[QB][PC];
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf, KVB);
+                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf, KVB, std::true_type{});
                     pv_part(sk + TILE, c, pf, KVB);
                 }
                 __syncthreads();
@@ -452,20 +468,209 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Decode attention (few query rows against a long KV cache; batch-1 decode packs the G query heads of a KV group as G <= 16 query
+// rows of one "head", llm.py _decode_one / DecodeGraph): HBM-bound, 2.8 GB of K/V per token at a 49 k context.  k_attn above serves
+// this shape with one workgroup per (head, split) in which only wave 0 has queries and ONE 64-row tile is in flight behind a block
+// barrier (4.4 TB/s).  Here every WAVE is an independent stream over its own contiguous run of 32-row chunks - no block barrier in
+// the loop - and keeps about three chunks (48 KB) in flight:
+//   K: straight from global memory into MFMA A-operand registers (a 16 x 32 fragment is 16 bytes per lane; each element is used
+//      once, so staging it in LDS would only add traffic), two register sets, re-issued as soon as the S MFMAs have consumed them;
+//   V: buffer_load ... lds into a per-wave ring of three 8 KiB stages (P.V needs V transposed: ds_read_b64_tr_b16), completion by a
+//      counted s_waitcnt vmcnt - the loads of a wave retire in order;
+//   rows past the wave's range are outside the buffer resource's extent: zeros, no memory traffic (the row part of every address
+//   stays in the VGPR offset, which is what the range check covers).
+// Exact online softmax per chunk (the loop is bandwidth-bound, the VALU work is free).  The four waves of a workgroup cover four
+// consecutive quarters of one split; they merge their (O, m, l) through LDS at the end, so a workgroup leaves ONE partial per split
+// in the layout k_attn_combine reads: half as many partials as before at the same number of waves streaming.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DCH = 32;                            // kv rows per chunk
+constexpr int DEC_STAGES = 3;
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+                                                        const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
+                                                        const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one V chunk (8 KiB at Dh = 128)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit, h = bh % Hq, b = bh / Hq;
+    const int hk = h / (Hq / Hkv);
+    const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
+    // chunks of this split, then of this wave
+    const int nch = (kv_valid + DCH - 1) / DCH, cps = (nch + nsplit - 1) / nsplit;
+    const int s_lo = min(split * cps, nch), s_hi = min(s_lo + cps, nch);
+    const int cpw = (s_hi - s_lo + 3) >> 2;
+    const int c_lo = min(s_lo + wave * cpw, s_hi), c_hi = min(c_lo + cpw, s_hi);
+    const int row_end = min(c_hi * DCH, kv_valid);                                      // rows of this wave: [c_lo * 32, row_end)
+
+    // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements)
+    sc_h8 qf[DS];
+    {
+        const int qr = rl < Sq ? rl : Sq - 1;
+        const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+    }
+    const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
+    const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
+    const int k_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldv + DH) * 2u) : 0;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kbase), 0, c_lo < c_hi ? k_ext : 0, 0x00020000);
+    // per-lane offsets inside a chunk: K fragment (kvb, ds) = row kvb*16 + rl, 16 bytes at element (ds*4 + g)*8;
+    // V granule j*64 + lane = row j*4 + (lane>>4), 16-byte slot (lane&15) ^ ((row&7)<<1)   (the swizzle the transpose reads below undo)
+    unsigned k_vo[2], v_vo[8];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) k_vo[kvb] = ((unsigned)(kvb * 16 + rl) * (unsigned)ldk + (unsigned)(g * 8)) * 2u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int vr = j * 4 + (lane >> 4); v_vo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)(((lane & 15) ^ ((vr & 7) << 1)) * 8)) * 2u; }
+    char* vring = smem + wave * (DEC_STAGES * CHB);
+    const unsigned vbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (DEC_STAGES * CHB));
+    const int vrow = 4 * g + (rl >> 2);
+    int v_off[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) v_off[db] = vrow * VROW + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+
+    auto issue = [&](int c, sc_u4 (&kr)[2][DS]) {              // 2*DS register loads + 8 LDS-DMA = 16 vm ops at Dh = 128, in this order
+        const unsigned ro_k = (unsigned)c * (unsigned)(DCH * ldk * 2), ro_v = (unsigned)c * (unsigned)(DCH * ldv * 2);
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) kr[kvb][ds] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (int)(ro_k + k_vo[kvb] + ds * 64), 0, 0);
+        char* dst = vring + (c % DEC_STAGES) * CHB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_load16(vbase, c < c_hi ? v_ext : 0, dst + j * 1024, ro_v + v_vo[j], 0);
+    };
+
+    sc_f4 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto compute = [&](int c, sc_u4 (&kr)[2][DS], auto reissue) {
+        // ---- S^T = K . Q^T for the 32 rows (this consumes the K registers) ----
+        sc_f4 s[2];
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb) {
+            s[kvb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) s[kvb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, kr[kvb][ds]), qf[ds], s[kvb], 0, 0, 0);
+        }
+        // the MFMAs above have READ kr; make that visible to the scheduler before the registers are loaded again
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        reissue();
+        // ---- exact online-softmax step ----
+        const int kv0 = c * DCH + g * 4;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kvb][r] = (kv0 + kvb * 16 + r < row_end) ? s[kvb][r] : -INFINITY;
+                tmax = fmaxf(tmax, s[kvb][r]);
+            }
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto bsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1])) * scale_log2;
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] *= alpha;
+        sc_h8 pf;
+        float ps = 0.f;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][r], scale_log2, -m_use));
+                ps += p;
+                pf[kvb * 4 + r] = (_Float16)p;
+            }
+        l_run += ps;
+        // ---- O^T += V^T . P^T : the V chunk must have landed (everything issued after it may stay in flight: 16 vm ops per chunk) ----
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DS + 8) : "memory");
+        // The transpose reads are inline asm: behind a builtin LDS read hipcc puts s_waitcnt vmcnt(0) (the LDS-DMA of later chunks "may
+        // alias" it), which would drain the whole prefetch queue on every chunk.  The stages of the ring are disjoint by construction.
+        const unsigned sa = vbase_lds + (unsigned)((c % DEC_STAGES) * CHB);
+        sc_s4 lo[DB], hi[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[db]) : "v"(sa + (unsigned)v_off[db]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[db]) : "v"(sa + (unsigned)v_off[db]), "n"(16 * VROW));
+        }
+        static_assert(DB == 8, "the lgkmcnt fence below names 16 registers");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
+                                              "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            typedef short sc_s8 __attribute__((ext_vector_type(8)));
+            const sc_s8 v8 = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi[db][0], hi[db][1], hi[db][2], hi[db][3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, v8), pf, o[db], 0, 0, 0);
+        }
+    };
+
+    // ---- the stream: chunks c_lo .. c_hi - 1; chunk c + 2 is requested right after the S MFMAs of chunk c ----
+    sc_u4 ka[2][DS], kb[2][DS];
+    if (c_lo < c_hi) {
+        issue(c_lo, ka);
+        issue(c_lo + 1, kb);                       // (past c_hi: zero extent -> no traffic)
+        for (int c = c_lo; c < c_hi; c += 2) {
+            compute(c, ka, [&] { issue(c + 2, ka); });
+            if (c + 1 < c_hi) compute(c + 1, kb, [&] { issue(c + 3, kb); });
+            else break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the ring is reused / the block ends
+    // ---- merge the four waves of the split through LDS (aliases the V rings: every wave is done with its own) ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* mo = reinterpret_cast<float*>(smem);             // [4][DH][16] O^T, then [4][16] m, [4][16] l
+    float* mm = mo + 4 * DH * 16;
+    float* ml = mm + 64;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[(wave * DH + db * 16 + g * 4 + r) * 16 + rl] = o[db][r];
+    if (g == 0) { mm[wave * 16 + rl] = m_run; ml[wave * 16 + rl] = l_run; }
+    __syncthreads();
+    for (int e = tid; e < Sq * DH; e += 256) {
+        const int q = e / DH, d = e - q * DH;
+        float M = fmaxf(fmaxf(mm[q], mm[16 + q]), fmaxf(mm[32 + q], mm[48 + q]));
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[w * 16 + q];
+            const float wt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+            acc += mo[(w * DH + d) * 16 + q] * wt;
+            l += ml[w * 16 + q] * wt;
+        }
+        float* pp = part + ((((size_t)b * Hq + h) * Sq + q) * nsplit + split) * (DH + 2);
+        pp[d] = acc;
+        if (d == 0) { pp[DH] = M; pp[DH + 1] = l; }
+    }
+}
+
 template <int DH, int QB, int CH = 64>
 int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
-                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s) {
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s,
+                bool pre) {
     const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16), G = Hq / Hkv;
     const int npairs = nqb * Hkv * B;
     const dim3 grid((unsigned)(((npairs + 7) / 8) * 8 * G * nsplit)), block(256);
     const size_t lds = 2 * 2 * KVT * DH * 2;
     const float sl2 = scale * 1.4426950408889634f;
-    if (causal)
-        hipLaunchKernelGGL((k_attn<DH, QB, true, CH>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
-    else
-        hipLaunchKernelGGL((k_attn<DH, QB, false, CH>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v,
-                           ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs);
+#define SC_LA(C, P) hipLaunchKernelGGL((k_attn<DH, QB, C, CH, P>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v, \
+                                       ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs)
+    if (causal) { if (pre) SC_LA(true, true); else SC_LA(true, false); }
+    else { if (pre) SC_LA(false, true); else SC_LA(false, false); }
+#undef SC_LA
     if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH * (1024 / DH < 8 ? 1024 / DH : 8)), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
     SC_CHECK_LAUNCH("sc_attention_f16");
     return SC_OK;
@@ -473,25 +678,24 @@ int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, i
 
 }  // namespace
 
-// attention_fat.hip: hand-scheduled long-prefill kernel (Dh = 128, 256 queries per workgroup, no split-KV)
-int sc_attn_fat_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv, int Hq, int Hkv,
-                       float scale, int causal, const int32_t* kv_len, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s);
-
-static bool attn_fat_enabled() {
-    static const bool fat = [] { const char* e = getenv("SC_ATTN_FAT"); return e && e[0] == '1'; }();
-    return fat;
+static bool attn_decode_enabled() {
+    static const bool on = [] { const char* e = getenv("SC_ATTN_DECODE"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 extern "C" int sc_attention_variant(int Dh, int Sq, int nsplit) {
-    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return attn_fat_enabled() ? 2 : 1;
+    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return 1;
+    if (Dh == 128 && nsplit > 1 && Sq <= 16 && attn_decode_enabled()) return 3;      // (non-causal calls; a causal call of this shape runs k_attn)
     return 0;
 }
 
 extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
-                                int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal, const int32_t* kv_len,
+                                int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal_flags, const int32_t* kv_len,
                                 int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, int64_t q_batch_stride,
                                 int64_t o_batch_stride, sc_stream_t stream) {
     SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
+    SC_REQUIRE((causal_flags & ~(1 | SC_ATTN_Q_PRESCALED)) == 0, "sc_attention_f16: unknown bits in the causal / flags argument");
+    const int causal = causal_flags & 1;
     SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
     SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
     SC_REQUIRE(!causal || Skv >= Sq, "sc_attention_f16: causal needs Skv >= Sq");
@@ -510,15 +714,26 @@ extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, 
     SC_REQUIRE(qhs % 8 == 0 && ohs % 4 == 0, "sc_attention_f16: head strides must be multiples of 8 (q) / 4 (out)");
     const long qbs = q_batch_stride > 0 ? (long)q_batch_stride : (long)Sq * ldq, obs = o_batch_stride > 0 ? (long)o_batch_stride : (long)Sq * ldo;
     SC_REQUIRE(qbs % 8 == 0 && obs % 4 == 0, "sc_attention_f16: batch strides must be multiples of 8 (q) / 4 (out)");
-    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
-    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles.
-    // SC_ATTN_FAT=1 selects the hand-scheduled 32x32x16 kernel of attention_fat.hip instead: it keeps the matrix pipe 69 % busy
-    // against 57 %, but both kernels sit on the 1400 W package power cap (1.70 vs 1.87 GHz sustained) and deliver the same
-    // 1.17-1.19 PFLOP/s (tools/power_probe.py, profiles/r02_run31_power_probe.log), so the simpler kernel stays the default
-    if (sc_attention_variant(Dh, Sq, nsplit) == 2) {
-        return sc_attn_fat_launch(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, qhs, ohs, qbs, obs, s);
+    // few query rows against a long cache with split-KV = a decode step: the per-wave streaming kernel (SC_ATTN_DECODE=0: the tile kernel)
+    const bool pre = (causal_flags & SC_ATTN_Q_PRESCALED) != 0;
+    const float sl2_dec = pre ? 1.0f : scale * 1.4426950408889634f;
+    if (sc_attention_variant(Dh, Sq, nsplit) == 3 && !causal) {
+        constexpr int LDS_DEC = 4 * DEC_STAGES * DCH * 128 * 2;
+        static bool attr_done[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
+        hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)(B * Hq * nsplit)), dim3(256), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
+                           (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, sl2_dec, kv_len, part, nsplit, qhs, qbs);
+        hipLaunchKernelGGL((k_attn_combine<128>), dim3((unsigned)(B * Hq * Sq)), dim3(1024), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, ohs, obs);
+        SC_CHECK_LAUNCH("sc_attention_f16");
+        return SC_OK;
     }
-    if (sc_attention_variant(Dh, Sq, nsplit) == 1) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
-    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
-    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s);
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles.
+    // (The hand-scheduled one-wave-per-SIMD k_attn_fat of round 2 kept the matrix pipe busier and delivered the same TFLOP/s under the
+    // board's power cap; it was removed in round 3 - see DESIGN.md section 4.)
+    if (sc_attention_variant(Dh, Sq, nsplit) == 1) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
 }

@@ -531,7 +531,8 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
-                                                     void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM, int ntiles) {
+                                                     void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM, int ntiles,
+                                                     const float* __restrict__ tab, int pos0, int lead_cols, float col_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // virtual block vb -> tile (same XCD-aware grouped order for the one-tile-per-workgroup launch and the persistent walk
     // vb = blockIdx.x, + gridDim.x, ...; gridDim.x is a multiple of 8 there, so a workgroup stays on the XCD slice of its tiles)
@@ -736,6 +737,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     } else {
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
         const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
+        // SC_EPI_COLSCALE: the wave's 128 columns are scaled if they lie in [0, lead_cols) (the query third of a fused q|k|v projection
+        // carries the softmax scale * log2 e into sc_attention_f16's pre-scaled mode: applied to the fp32 sum, ONE rounding)
+        const float cscale = (EPI == SC_EPI_COLSCALE && n0 < lead_cols) ? col_scale : 1.0f;
         // one step = a column pair (two 16-column tiles) x four row tiles: bias + activation + residual, 16-byte stores
         auto step = [&](int st, const sc_u2 (&rr)[4][2]) {
             const int pr = st >> 1, mh = st & 1;
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                     float v[4], r4[4];
                     h4f(rr[mq][h], r4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epi_apply(acc[mi][nj][e] + bv[h][e], EPI) + r4[e];
+                    for (int e = 0; e < 4; ++e) v[e] = (EPI == SC_EPI_COLSCALE ? (acc[mi][nj][e] + bv[h][e]) * cscale : epi_apply(acc[mi][nj][e] + bv[h][e], EPI)) + r4[e];
                     (h ? hi : lo)[0] = pack2(v[0], v[1]);
                     (h ? hi : lo)[1] = pack2(v[2], v[3]);
                 }
@@ -775,7 +779,64 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 for (int h = 0; h < 2; ++h)
                     rr[mq][h] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rl_e * ldr + g_e * 4) * 2 + (mh * 4 + mq) * rstep_r, (2 * pr + h) * 32, 0);
         };
-        if (R) {
+        if (EPI == SC_EPI_ROPE && n0 < lead_cols) {
+            // Rotary epilogue (Qwen2 q / k projections): the wave's 128 columns are ONE head; rotate-half pairs column j with j + 64, i.e.
+            // the 16-column tile nj with nj + 4 of the SAME lane.  x' = (x_j cos - x_{j+64} sin, x_{j+64} cos + x_j sin) on the fp32
+            // accumulators + bias with the fp32 table row of the token's position (row m -> position pos0 + m; [cos(64) | sin(64)], the
+            // query table pre-multiplied by the softmax scale * log2 e), rounded to fp16 once.  Same arithmetic as k_rope_f32in
+            // (llm_ops.hip) and k_decode_qkv<true> (gemv.hip).
+            const __amdgpu_buffer_rsrc_t rs_t = uniform_rsrc(tab + (size_t)(pos0 + m0) * 128, rv * 512);
+            int rstep_t = 16 * 512;
+            asm volatile("" : "+v"(rstep_t));
+            auto load_tab = [&](int st, sc_u4 (&cs)[2], sc_u4 (&sn)[2]) {          // one step = ONE row tile x (two column tiles + their partners)
+                const int pr = st >> 3, mi = st & 7;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    cs[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (rl_e * 128 + g_e * 4) * 4 + mi * rstep_t, (2 * pr + h) * 64, 0);
+                    sn[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (rl_e * 128 + g_e * 4) * 4 + mi * rstep_t, (2 * pr + h) * 64 + 256, 0);
+                }
+            };
+            auto rstep = [&](int st, const sc_u4 (&cs)[2], const sc_u4 (&sn)[2]) {
+                const int pr = st >> 3, mi = st & 7;
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned la[2], ha[2], lb[2], hb[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nj = 2 * pr + h;
+                    float ba[4], bb[4];
+                    h4f(*reinterpret_cast<const sc_u2*>(bslot + nj * 32), ba);
+                    h4f(*reinterpret_cast<const sc_u2*>(bslot + (nj + 4) * 32), bb);
+                    const sc_f4 c4 = __builtin_bit_cast(sc_f4, cs[h]), s4 = __builtin_bit_cast(sc_f4, sn[h]);
+                    float oa[4], ob[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[mi][nj][e] + ba[e], b = acc[mi][nj + 4][e] + bb[e];
+                        oa[e] = __builtin_fmaf(-b, s4[e], a * c4[e]);
+                        ob[e] = __builtin_fmaf(a, s4[e], b * c4[e]);
+                    }
+                    (h ? ha : la)[0] = pack2(oa[0], oa[1]); (h ? ha : la)[1] = pack2(oa[2], oa[3]);
+                    (h ? hb : lb)[0] = pack2(ob[0], ob[1]); (h ? hb : lb)[1] = pack2(ob[2], ob[3]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(la[0], ha[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(la[1], ha[1], false, false);
+                unsigned w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];          // (store / s_nop pairing: see the note in step())
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl_e * ldc + (g_e & 1) * 16 + (g_e >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32, 0);
+                asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                const auto t0 = __builtin_amdgcn_permlane16_swap(lb[0], hb[0], false, false);
+                const auto t1 = __builtin_amdgcn_permlane16_swap(lb[1], hb[1], false, false);
+                unsigned x0 = t0[0], x1 = t1[0], x2 = t0[1], x3 = t1[1];
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{x0, x1, x2, x3}, rs_c, (rl_e * ldc + (g_e & 1) * 16 + (g_e >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32 + 128, 0);
+                asm volatile("s_nop 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            };
+            sc_u4 ca[2], sa[2], cb[2], sb[2];
+            load_tab(0, ca, sa);
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                load_tab(st + 1, cb, sb); rstep(st, ca, sa);
+                if (st + 2 < 16) load_tab(st + 2, ca, sa);
+                rstep(st + 1, cb, sb);
+            }
+        } else if (R) {
             // the residual of step st + 1 is requested BEFORE the stores of step st are issued: vmcnt retires in order, so a load issued
             // behind stores could only be consumed after those stores have completed (write latency exposed on every step)
             sc_u2 ra[4][2], rb[4][2];
@@ -952,9 +1013,9 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
                 fattr[dev][EPI][fp] = true;
             }
             if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                                       (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
+                                       (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
             else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                                    (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all);
+                                    (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
         }
@@ -989,6 +1050,52 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
 }
 
 }  // namespace
+
+namespace {
+template <int EPI>
+int launch_headed(const void* A, int lda, const void* W, const void* bias, void* C, int ldc, int M, int N, int K, const float* tab, int pos0, int lead_cols,
+                  float col_scale, hipStream_t s) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    static int n_cu_dev[16] = {};
+    if (n_cu_dev[dev] == 0) {
+        int cur = 0, n = 0;
+        if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
+        if (n_cu_dev[dev] <= 0) n_cu_dev[dev] = 256;
+    }
+    const int n_cu = n_cu_dev[dev], tM = (M + BM2 - 1) / BM2, tN = N / BN2, nt_all = tM * tN;
+    const bool fp = nt_all > n_cu;                                   // persistent walk once there are more tiles than CUs (as in launch_gemm)
+    const int gm_sel = tN > 16 ? 4 : SC_GEMM_GM;
+    static bool attr[16][2] = {};
+    if (!attr[dev][fp]) {
+        (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
+        attr[dev][fp] = true;
+    }
+    if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                               (const _Float16*)nullptr, 0, C, ldc, M, N, K, tN, gm_sel, nt_all, tab, pos0, lead_cols, col_scale);
+    else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), dim3((unsigned)nt_all), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+                            (const _Float16*)nullptr, 0, C, ldc, M, N, K, tN, gm_sel, nt_all, tab, pos0, lead_cols, col_scale);
+    SC_CHECK_LAUNCH("sc_gemm_headed_f16");
+    return SC_OK;
+}
+}  // namespace
+
+// C = headed_epilogue(A W^T + bias): the GEMM whose epilogue knows that the output columns are heads of width 128 (hand-scheduled kernel only)
+extern "C" int sc_gemm_headed_f16(const void* A, int lda, const void* W, const void* bias, void* C, int ldc, int M, int N, int K, int mode,
+                                  const float* rope_tab, int pos0, int lead_cols, float col_scale, sc_stream_t stream) {
+    SC_REQUIRE(A && W && C, "sc_gemm_headed_f16: null pointer argument");
+    SC_REQUIRE(M > 0 && N > 0 && K > 0 && lead_cols >= 0 && lead_cols <= N && lead_cols % 128 == 0, "sc_gemm_headed_f16: bad sizes (lead_cols: a multiple of 128 within N)");
+    SC_REQUIRE(mode == SC_EPI_ROPE || mode == SC_EPI_COLSCALE, "sc_gemm_headed_f16: mode must be SC_EPI_ROPE or SC_EPI_COLSCALE");
+    SC_REQUIRE(mode != SC_EPI_ROPE || (rope_tab && pos0 >= 0 && (reinterpret_cast<uintptr_t>(rope_tab) & 15) == 0), "sc_gemm_headed_f16: SC_EPI_ROPE needs a 16-byte aligned table and pos0 >= 0");
+    // what the hand-scheduled kernel serves (the caller's other route: sc_gemm_f16 with out_f32 = 1, then sc_rope_f32in_f16 - same numbers)
+    if (!(N % BN2 == 0 && K % 128 == 0 && lda >= K && lda % 8 == 0 && (size_t)lda * 512 < (1ull << 31) && ldc >= N && ldc % 8 == 0 &&
+          ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0))
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_gemm_headed_f16: needs N %% 256 == 0, K %% 128 == 0, lda %% 8 == 0, ldc %% 8 == 0 and 16-byte aligned A / W / C / bias");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == SC_EPI_ROPE) return launch_headed<SC_EPI_ROPE>(A, lda, W, bias, C, ldc, M, N, K, rope_tab, pos0, lead_cols, 1.0f, s);
+    return launch_headed<SC_EPI_COLSCALE>(A, lda, W, bias, C, ldc, M, N, K, nullptr, 0, lead_cols, col_scale, s);
+}
 
 extern "C" int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const void* residual, int ldr, void* C, int ldc,
                            int M, int N, int K, int epilogue, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, sc_stream_t stream) {

@@ -8,6 +8,35 @@
 
 namespace {
 
+// Qwen2 RMSNorm of the activation vector, ONCE per workgroup, into LDS (fp16, HF's rounding: gamma * fp16(x * rstd)): the 256 threads
+// share the sum of squares (fixed reduction order: 8-element chunks t, t + 256, ... per thread, xor-shuffle tree per wave, the four
+// wave sums added in order) and each writes its chunks of the normalised vector.  Before (round 2) every WAVE recomputed the norm and
+// re-normalised x in every K-step of its weight stream - ~40 VALU instructions per 16-byte weight load in an in-order loop, and the
+// weight loads could not start before the wave's own reduction was done (k_decode_qkv: 2.6 TB/s, gate/up: 51 us against 44 without
+// the fused norm).  Shared by k_gemv<NORM> and k_decode_qkv so that the eager decode step and the captured graph stay bit-identical.
+__device__ __forceinline__ void block_rmsnorm_to_lds(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma, int K, float eps, _Float16* xn,
+                                                     float* red) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float ss = 0.f;
+    for (int k = t * 8; k < K; k += 2048) {
+        const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
+    for (int k = t * 8; k < K; k += 2048) {
+        const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k), gv = *reinterpret_cast<const sc_h8*>(gamma + k);
+        sc_h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)gv[e] * (float)(_Float16)((float)xv[e] * rstd));
+        *reinterpret_cast<sc_h8*>(xn + k) = o;
+    }
+    __syncthreads();
+}
 
 template <bool SWIGLU, bool OUT_F32, int RPW, int UNR = 4>
 __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
@@ -15,37 +44,52 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
                                               const int* __restrict__ y_row, int y_ld, const _Float16* __restrict__ gamma, float eps) {
     // optional dynamic output row (KV-cache append at a device-resident position: keeps a decode step hipGraph-replayable)
     void* y = y_row ? (void*)(reinterpret_cast<_Float16*>(y_base) + (size_t)y_row[0] * (size_t)y_ld) : y_base;
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-    if (row0 >= N) return;
     float acc[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
-    // optional fused Qwen2 RMSNorm of x (gamma != NULL): every wave recomputes rsqrt(mean(x^2) + eps) from the L1-resident x and
-    // normalises on the fly with HF's rounding (gamma * fp16(x * rstd)) — removes a latency-bound one-wave kernel per projection
-    float rstd = 1.f;
-    if (gamma) {
-        float ss = 0.f;
-        for (int k = lane * 8; k < K; k += 512) {
-            const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
-        rstd = rsqrtf(ss / (float)K + eps);
-    }
     const _Float16* wp[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
-#pragma unroll UNR
-    for (int k = lane * 8; k < K; k += 512) {                       // (unrolled: >= 4 weight loads in flight per lane at RPW = 1)
-        sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
-        if (gamma) {
-            const sc_h8 gv = *reinterpret_cast<const sc_h8*>(gamma + k);
+    // optional fused Qwen2 RMSNorm of x (gamma != NULL): the workgroup normalises x once into LDS (block_rmsnorm_to_lds) and the weight
+    // stream below reads the finished vector; the first weight loads of every row are requested BEFORE that, so that the norm's
+    // load -> reduce -> barrier chain runs under their latency instead of in front of it
+    constexpr int PF = RPW >= 4 ? 2 : 4;                           // K-slices requested ahead of the norm
+    _Float16* xn = reinterpret_cast<_Float16*>(gemv_smem);
+    sc_h8 w0[PF][RPW];
+    if (gamma) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = (_Float16)((float)gv[e] * (float)(_Float16)((float)xv[e] * rstd));
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                w0[u][r] = lane * 8 + u * 512 < K ? __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp[r] + u * 512)) : sc_h8{0, 0, 0, 0, 0, 0, 0, 0};
+        block_rmsnorm_to_lds(x, gamma, K, eps, xn, reinterpret_cast<float*>(gemv_smem + (size_t)K * 2));
+    }
+    if (row0 >= N) return;                                        // (after the barriers of the norm)
+    auto ldx = [&](int k) { return gamma ? *reinterpret_cast<const sc_h8*>(xn + k) : *reinterpret_cast<const sc_h8*>(x + k); };
+    int kb = lane * 8;
+    if (gamma) {                                                  // the K-slices requested ahead
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (kb < K) {
+                const sc_h8 xv = *reinterpret_cast<const sc_h8*>(xn + kb);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const sc_h2 a = {w0[u][r][e], w0[u][r][e + 1]}, b = {xv[e], xv[e + 1]};
+                        acc[r] = __builtin_amdgcn_fdot2(a, b, acc[r], false);
+                    }
+                }
+                kb += 512;
+            }
         }
+    }
+#pragma unroll UNR
+    for (int k = kb; k < K; k += 512) {                             // (unrolled: >= 4 weight loads in flight per lane at RPW = 1)
+        const sc_h8 xv = ldx(k);
         sc_h8 wv[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp[r] + (k - lane * 8)));
@@ -89,43 +133,59 @@ __global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, co
 // One wave owns the two rows (h, j) and (h, j + Dh/2) of a head, i.e. one RoPE rotation pair, so the rotation happens in the
 // epilogue of lane 0 with the arithmetic of k_rope_qk_row (llm_ops.hip: fp32 trig, cos / sin and every product rounded to fp16 like
 // HF's apply_rotary_pos_emb) on the fp16-rounded projections: bit-identical to the three-launch path.  V rows ride along unrotated.
+// TAB: the rotation uses the fp32 cos / sin tables of sc_rope_table_f32 (tab_q carries the softmax scale * log2 e: the query leaves
+// pre-scaled for sc_attention_f16's SC_ATTN_Q_PRESCALED mode) on the fp32 accumulators + bias, rounded to fp16 ONCE - the numerics of
+// the prefill GEMM's rotary epilogue (gemm.hip) and of k_rope_f32in.
+template <bool TAB>
 __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__ Wq, const _Float16* __restrict__ Wkv, const _Float16* __restrict__ bq,
                                                     const _Float16* __restrict__ bkv, const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
                                                     float eps, _Float16* __restrict__ q_out, _Float16* __restrict__ cache, int ld,
-                                                    const int* __restrict__ pos, int Hq, int Hkv, int Dh, int K, float log2_theta) {
+                                                    const int* __restrict__ pos, int Hq, int Hkv, int Dh, int K, float log2_theta,
+                                                    const float* __restrict__ tab_q, const float* __restrict__ tab_k) {
     const int lane = threadIdx.x & 63;
     const int half = Dh >> 1;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);                 // (head, j) over q heads, then k heads, then v heads
     const int ntask = (Hq + 2 * Hkv) * half;
-    if (task >= ntask) return;
-    const int hh = task / half, j = task - hh * half;
+    const bool live = task < ntask;                                       // (dead waves of the last workgroup still take part in the norm's barriers)
+    const int hh = (live ? task : 0) / half, j = (live ? task : 0) - hh * half;
     const _Float16 *w0, *b0;
     int kind, h;                                                          // 0 = q, 1 = k, 2 = v
     if (hh < Hq) { kind = 0; h = hh; w0 = Wq + (size_t)(h * Dh + j) * (size_t)K; b0 = bq ? bq + h * Dh + j : nullptr; }
     else if (hh < Hq + Hkv) { kind = 1; h = hh - Hq; w0 = Wkv + (size_t)(h * Dh + j) * (size_t)K; b0 = bkv ? bkv + h * Dh + j : nullptr; }
     else { kind = 2; h = hh - Hq - Hkv; w0 = Wkv + (size_t)((Hkv + h) * Dh + j) * (size_t)K; b0 = bkv ? bkv + (Hkv + h) * Dh + j : nullptr; }
     const _Float16* w1 = w0 + (size_t)half * (size_t)K;
-    float rstd = 1.f;
-    if (gamma) {
-        float ss = 0.f;
-        for (int k = lane * 8; k < K; k += 512) {
-            const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+    // RMSNorm of x once per workgroup into LDS; the first four K-slices of both weight rows are requested before it (see k_gemv)
+    extern __shared__ __attribute__((aligned(16))) char qkv_smem[];
+    _Float16* xn = reinterpret_cast<_Float16*>(qkv_smem);
+    constexpr int PF = 4;
+    sc_h8 pa[PF], pb[PF];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
-        rstd = rsqrtf(ss / (float)K + eps);
+    for (int u = 0; u < PF; ++u) {
+        const int k = lane * 8 + u * 512;
+        pa[u] = (live && k < K) ? __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w0 + k)) : sc_h8{0, 0, 0, 0, 0, 0, 0, 0};
+        pb[u] = (live && k < K) ? __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w1 + k)) : sc_h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
+    if (gamma) block_rmsnorm_to_lds(x, gamma, K, eps, xn, reinterpret_cast<float*>(qkv_smem + (size_t)K * 2));
+    if (!live) return;
+    auto ldx = [&](int k) { return gamma ? *reinterpret_cast<const sc_h8*>(xn + k) : *reinterpret_cast<const sc_h8*>(x + k); };
     float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 4
-    for (int k = lane * 8; k < K; k += 512) {
-        sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
-        if (gamma) {
-            const sc_h8 gv = *reinterpret_cast<const sc_h8*>(gamma + k);
+    int kb = lane * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = (_Float16)((float)gv[e] * (float)(_Float16)((float)xv[e] * rstd));
+    for (int u = 0; u < PF; ++u) {
+        if (kb < K) {
+            const sc_h8 xv = ldx(kb);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const sc_h2 b = {xv[e], xv[e + 1]};
+                acc0 = __builtin_amdgcn_fdot2(sc_h2{pa[u][e], pa[u][e + 1]}, b, acc0, false);
+                acc1 = __builtin_amdgcn_fdot2(sc_h2{pb[u][e], pb[u][e + 1]}, b, acc1, false);
+            }
+            kb += 512;
         }
+    }
+#pragma unroll 4
+    for (int k = kb; k < K; k += 512) {
+        const sc_h8 xv = ldx(k);
         const sc_h8 wa = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w0 + k));
         const sc_h8 wb = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(w1 + k));
 #pragma unroll
@@ -142,6 +202,14 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
         const _Float16 a = (_Float16)(acc0 + (b0 ? (float)b0[0] : 0.f)), b = (_Float16)(acc1 + (b0 ? (float)b0[half] : 0.f));
         _Float16* dst = kind == 0 ? q_out + h * Dh + j : cache + (size_t)row * (size_t)ld + (kind == 1 ? 0 : Hkv * Dh) + h * Dh + j;
         if (kind == 2) { dst[0] = a; dst[half] = b; return; }
+        if (TAB) {
+            const float a32 = acc0 + (b0 ? (float)b0[0] : 0.f), b32 = acc1 + (b0 ? (float)b0[half] : 0.f);
+            const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)row * (size_t)Dh;
+            const float cs = t[j], sn = t[half + j];
+            dst[0] = (_Float16)__builtin_fmaf(-b32, sn, a32 * cs);
+            dst[half] = (_Float16)__builtin_fmaf(a32, sn, b32 * cs);
+            return;
+        }
         const float inv_freq = exp2f(-log2_theta * (float)(2 * j) / (float)Dh);
         float sn, cs;
         sincosf((float)row * inv_freq, &sn, &cs);
@@ -164,10 +232,26 @@ extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
-    hipLaunchKernelGGL(k_decode_qkv, dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+    hipLaunchKernelGGL(k_decode_qkv<false>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
-                       cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta));
+                       cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta), (const float*)nullptr, (const float*)nullptr);
     SC_CHECK_LAUNCH("sc_decode_qkv_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma, float rms_eps,
+                                     void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh, int K,
+                                     const float* tab_q, const float* tab_k, sc_stream_t stream) {
+    SC_REQUIRE(Wq && Wkv && x && q_out && cache && pos && tab_q && tab_k, "sc_decode_qkv_tab_f16: null pointer argument");
+    SC_REQUIRE(q_heads > 0 && kv_heads > 0 && Dh > 0 && Dh % 2 == 0 && K > 0 && K % 8 == 0, "sc_decode_qkv_tab_f16: bad sizes");
+    SC_REQUIRE(cache_ld >= 2 * kv_heads * Dh, "sc_decode_qkv_tab_f16: cache row stride too small for K | V");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
+               "sc_decode_qkv_tab_f16: weights, x and gamma must be 16-byte aligned");
+    const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
+    hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+                       (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
+                       cache_ld, pos, q_heads, kv_heads, Dh, K, 0.f, tab_q, tab_k);
+    SC_CHECK_LAUNCH("sc_decode_qkv_tab_f16");
     return SC_OK;
 }
 
@@ -183,6 +267,8 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     const _Float16 *w = (const _Float16*)W, *xx = (const _Float16*)x, *b = (const _Float16*)bias, *r = (const _Float16*)residual;
     // rows per wave: 4 amortises the x loads when there are plenty of rows; 1 keeps >= ~900 workgroups in flight for the
     // 3584-row projections (224 workgroups at 4 rows/wave left most CUs with a single latency-bound workgroup)
+    const size_t gsm = rms_gamma ? (size_t)K * 2 + 16 : 0;          // the normalised activation vector + 4 wave sums (block_rmsnorm_to_lds)
+    SC_REQUIRE(gsm <= 65536, "sc_gemv_f16: fused RMSNorm needs K <= 32760");
     const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
     static int rpw_few = -1;                        // SC_GEMV_RPW_FEW=1|2|4: rows per wave of the small projections (A/B runs)
     if (rpw_few < 0) { const char* e = getenv("SC_GEMV_RPW_FEW"); const int v = e ? atoi(e) : 1; rpw_few = (v == 2 || v == 4) ? v : 1; }   // anything else -> 1
@@ -193,16 +279,16 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     if (few && !out_f32 && (rpw == 2 || rpw == 4 || (rpw_few == 1 && K >= 8192))) {
         // long rows (the down projection, K = 18 944): two rows per wave and 8 x 16 B per lane in flight per row stream the 136 MB at
         // 5.56 TB/s against 5.11 (profiles/r02_run18: A/B of rows-per-wave x unroll on a >1 GB weight cycle); short rows: 1 row, unroll 4
-        if (rpw == 4) hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
-        else hipLaunchKernelGGL((k_gemv<false, false, 2, 8>), dim3((unsigned)((N + 7) / 8)), block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+        if (rpw == 4) hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+        else hipLaunchKernelGGL((k_gemv<false, false, 2, 8>), dim3((unsigned)((N + 7) / 8)), block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
         SC_CHECK_LAUNCH("sc_gemv_f16");
         return SC_OK;
     }
-    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
-    else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
-                        else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
-    else { if (few) hipLaunchKernelGGL((k_gemv<false, false, 1>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
-           else hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, 0, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
+    if (epilogue == SC_EPI_SWIGLU) hipLaunchKernelGGL((k_gemv<true, false, 4>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+    else if (out_f32) { if (few) hipLaunchKernelGGL((k_gemv<false, true, 1>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+                        else hipLaunchKernelGGL((k_gemv<false, true, 4>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
+    else { if (few) hipLaunchKernelGGL((k_gemv<false, false, 1>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+           else hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps); }
     SC_CHECK_LAUNCH("sc_gemv_f16");
     return SC_OK;
 }

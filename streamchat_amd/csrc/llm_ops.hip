@@ -111,6 +111,57 @@ __global__ __launch_bounds__(256) void k_rope_qk_row(_Float16* __restrict__ q, i
     *reinterpret_cast<sc_h4*>(base + half + i0) = ob;
 }
 
+// ---- RoPE from fp32 projections, ONE rounding (round 3) -------------------------------------------------------------------------
+// tab[pos][0][j] = cos(pos * theta^(-2j/Dh)) * scale, tab[pos][1][j] = sin(...) * scale, j < Dh/2 (fp32).  `scale` folds the softmax
+// scale * log2 e into the QUERY table: q' = rope(q) * scale is what sc_attention_f16 takes with SC_ATTN_Q_PRESCALED and needs no
+// per-score multiply; the key table has scale 1.  The rotation is applied to the fp32 accumulators + bias of the projection (GEMM
+// epilogue, the decode GEMV, or k_rope_f32in below for the small-M paths) and the result is rounded to fp16 ONCE - HF's fp16 path rounds
+// the projection, cos / sin, both products and the sum (what k_rope above reproduces); against an fp32 reference this is the closer one.
+__global__ __launch_bounds__(256) void k_rope_table(float* __restrict__ tab, int max_pos, int half, float log2_theta, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_pos * half) return;
+    const int pos = i / half, j = i - pos * half;
+    const float inv_freq = exp2f(-log2_theta * (float)(2 * j) / (float)(2 * half));
+    float sn, cs;
+    sincosf((float)pos * inv_freq, &sn, &cs);
+    tab[(size_t)pos * 2 * half + j] = cs * scale;
+    tab[(size_t)pos * 2 * half + half + j] = sn * scale;
+}
+
+// x [rows, ldx] fp32 = projection + bias -> out [rows, ldo] fp16: the first `heads` heads of width Dh rotated with the table row of the
+// row's position (positions[r] or pos0 + r), then `plain` further columns copied with a cast (the V part of a k|v projection)
+__global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x, int ldx, const float* __restrict__ tab, const int* __restrict__ pos, int pos0,
+                                                    int rows, int heads, int Dh, int plain, _Float16* __restrict__ out, int ldo) {
+    const int half = Dh / 2;
+    const int per_row = heads * (half / 4) + plain / 4;
+    const size_t total = (size_t)rows * per_row;
+    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(gi / per_row);
+        int rem = (int)(gi - (size_t)r * per_row);
+        const float* xr = x + (size_t)r * ldx;
+        _Float16* orow = out + (size_t)r * ldo;
+        if (rem >= heads * (half / 4)) {
+            const int c = heads * Dh + (rem - heads * (half / 4)) * 4;
+            const sc_f4 v = *reinterpret_cast<const sc_f4*>(xr + c);
+            *reinterpret_cast<sc_h4*>(orow + c) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            continue;
+        }
+        const int h = rem / (half / 4), i0 = (rem - h * (half / 4)) * 4;
+        const int p = pos ? pos[r] : pos0 + r;
+        const float* t = tab + (size_t)p * Dh;
+        const sc_f4 a = *reinterpret_cast<const sc_f4*>(xr + h * Dh + i0), b = *reinterpret_cast<const sc_f4*>(xr + h * Dh + half + i0);
+        const sc_f4 cs = *reinterpret_cast<const sc_f4*>(t + i0), sn = *reinterpret_cast<const sc_f4*>(t + half + i0);
+        sc_h4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oa[e] = (_Float16)__builtin_fmaf(-b[e], sn[e], a[e] * cs[e]);
+            ob[e] = (_Float16)__builtin_fmaf(a[e], sn[e], b[e] * cs[e]);
+        }
+        *reinterpret_cast<sc_h4*>(orow + h * Dh + i0) = oa;
+        *reinterpret_cast<sc_h4*>(orow + h * Dh + half + i0) = ob;
+    }
+}
+
 // out[b, y*g + x, d0..d0+7] = mean of in[b, (y*r + dy)*P + (x*r + dx), d0..d0+7] over the r x r window (fp32 accumulation)
 __global__ void k_avgpool_tokens(const _Float16* __restrict__ in, _Float16* __restrict__ out, int P, int D, int r, int g, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one thread = 8 channels of one output token
@@ -184,5 +235,28 @@ extern "C" int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, con
     hipLaunchKernelGGL(k_rope_qk_row, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (_Float16*)q, q_heads, (_Float16*)cache, ld,
                        row_index, kv_heads, Dh, log2f(theta));
     SC_CHECK_LAUNCH("sc_rope_qk_row_f16");
+    return SC_OK;
+}
+
+extern "C" int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, float scale, sc_stream_t stream) {
+    SC_REQUIRE(tab && max_pos > 0 && Dh > 0 && Dh % 8 == 0 && theta > 1.f, "sc_rope_table_f32: bad arguments");
+    const int n = max_pos * (Dh / 2);
+    hipLaunchKernelGGL(k_rope_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab, max_pos, Dh / 2, log2f(theta), scale);
+    SC_CHECK_LAUNCH("sc_rope_table_f32");
+    return SC_OK;
+}
+
+extern "C" int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, const int32_t* positions, int pos0, int rows, int heads, int Dh, int plain_cols,
+                                 void* out, int ldo, sc_stream_t stream) {
+    SC_REQUIRE(x && tab && out, "sc_rope_f32in_f16: null pointer argument");
+    SC_REQUIRE(rows > 0 && heads >= 0 && Dh > 0 && Dh % 8 == 0 && plain_cols >= 0 && plain_cols % 4 == 0 && ldx >= heads * Dh + plain_cols && ldx % 4 == 0 &&
+                   ldo >= heads * Dh + plain_cols && ldo % 4 == 0,
+               "sc_rope_f32in_f16: bad sizes");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(tab)) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+               "sc_rope_f32in_f16: x / table must be 16-byte aligned, out 8-byte");
+    const size_t total = (size_t)rows * (heads * (Dh / 8) + plain_cols / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rope_f32in, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, tab, positions, pos0, rows, heads, Dh, plain_cols, (_Float16*)out, ldo);
+    SC_CHECK_LAUNCH("sc_rope_f32in_f16");
     return SC_OK;
 }

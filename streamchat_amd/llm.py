@@ -8,6 +8,7 @@ re-running the full 26k-49k-token prefill for EVERY generated token (inference_s
 utiles.py:556,605); here the prompt is prefilled once into a resident KV cache and each new token is one decode step
 (greedy outputs are identical with and without a cache — SURVEY.md Appendix D)."""
 import types
+import os
 import typing
 
 import torch
@@ -87,6 +88,30 @@ class Qwen2Model:
     def embed_tokens(self, ids):
         return ops.gather_rows(ids.to(self.device).view(-1), self.embed)
 
+    # ---- rotary tables (round 3): RoPE is applied to the fp32 projection sums and rounded ONCE; the query table carries the softmax
+    # scale * log2 e, so q reaches sc_attention_f16 pre-scaled (SC_ATTN_Q_PRESCALED) - llm_ops.hip k_rope_table / gemm.hip rotary epilogue
+    def rope_tabs(self, n_pos=None):
+        c = self.cfg
+        n = max(self.max_seq, n_pos or 0)
+        return (ops.rope_table(n, c.head_dim, c.rope_theta, c.head_dim ** -0.5 * ops.LOG2E, self.device),
+                ops.rope_table(n, c.head_dim, c.rope_theta, 1.0, self.device))
+
+    def _qkv_rows(self, x, L, pos0, q_out, kv_out, positions=None):
+        """q_out <- rope(x wq^T + bq) * scale*log2e, kv_out <- [rope(k) | v] for the rows of x at positions pos0.. (or `positions`): the rotary
+        GEMM epilogue where the hand-scheduled kernel serves the shape, otherwise fp32 projections + k_rope_f32in - the same numbers."""
+        c = self.cfg
+        n, Dh, dq, dkv = x.shape[0], c.head_dim, c.heads * c.head_dim, c.kv_heads * c.head_dim
+        tq, tk = self.rope_tabs(pos0 + n)
+        fused = (positions is None and Dh == 128 and n >= 256 and ops.gemm_headed_ok(dq, x.shape[1], x, L["wq"], L["bq"], q_out)
+                 and ops.gemm_headed_ok(2 * dkv, x.shape[1], x, L["wkv"], L["bkv"], kv_out) and q_out.stride(0) % 8 == 0 and kv_out.stride(0) % 8 == 0)
+        if fused:
+            ops.gemm_headed(x, L["wq"], L["bq"], q_out, "rope", dq, tq, pos0)
+            ops.gemm_headed(x, L["wkv"], L["bkv"], kv_out, "rope", dkv, tk, pos0)
+        else:
+            ops.rope_f32in(ops.gemm(x, L["wq"], L["bq"], out_f32=True), tq, c.heads, Dh, q_out, 0, pos0, positions)
+            ops.rope_f32in(ops.gemm(x, L["wkv"], L["bkv"], out_f32=True), tk, c.kv_heads, Dh, kv_out, dkv, pos0, positions)
+        return q_out, kv_out
+
     def reset_cache(self, max_seq=None):
         c = self.cfg
         if max_seq is not None:
@@ -124,28 +149,30 @@ class Qwen2Model:
         tail = None
         for l, L in enumerate(self.L):
             x = ops.rmsnorm(h, L["ln1"], c.eps, out=B["x"][:n])
-            kv = ops.gemm(x, L["wkv"], L["bkv"], out=self.cache[l][pos0:S])
             if self.trim_last_layer and last_only and l == len(self.L) - 1:
                 # Only the last position's logits are wanted: in the LAST layer every row still contributes its K/V (cache), but
                 # the query, attention, output projection and MLP are needed for the final row alone (1/layers of the prefill
                 # flops saved; HF computes all rows and slices the logits afterwards - the returned row is the same).
-                ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
-                ql = ops.gemm(x[n - 1:n], L["wq"], L["bq"])
-                ops.rope_(ql, c.heads, Dh, c.rope_theta, S - 1)
+                tq, tk = self.rope_tabs(S)
+                kv = self.cache[l][pos0:S]
+                if Dh == 128 and n >= 256 and ops.gemm_headed_ok(2 * dkv, x.shape[1], x, L["wkv"], L["bkv"], kv):
+                    ops.gemm_headed(x, L["wkv"], L["bkv"], kv, "rope", dkv, tk, pos0)
+                else:
+                    ops.rope_f32in(ops.gemm(x, L["wkv"], L["bkv"], out_f32=True), tk, c.kv_heads, Dh, kv, dkv, pos0)
+                ql = ops.rope_f32in(ops.gemm(x[n - 1:n], L["wq"], L["bq"], out_f32=True), tq, c.heads, Dh,
+                                    torch.empty((1, dq), dtype=torch.float16, device=self.device), 0, S - 1)
                 ck = self.cache[l][:S]
                 nsplit = max(1, min(128, ((S + 63) // 64) // 2))
                 al = ops.attention(ql.unsqueeze(0), ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.heads, c.kv_heads, Dh, Dh ** -0.5,
-                                   causal=True, nsplit=nsplit).squeeze(0)
+                                   causal=True, nsplit=nsplit, q_prescaled=True).squeeze(0)
                 hl = ops.gemm(al, L["wo"], None, residual=h[n - 1:n])
                 ml = ops.gemm(ops.rmsnorm(hl, L["ln2"], c.eps), L["wgu"], None, epilogue="swiglu")
                 tail = ops.gemm(ml, L["wd"], None, residual=hl)
                 break
-            q = ops.gemm(x, L["wq"], L["bq"], out=B["q"][:n])
-            ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
-            ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)                       # K occupies columns [0, dkv) of the cache row
+            q, _ = self._qkv_rows(x, L, pos0, B["q"][:n], self.cache[l][pos0:S])      # K | V land in the cache rows; q pre-scaled
             ck = self.cache[l][:S]
             att = ops.attention(q.unsqueeze(0), ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.heads, c.kv_heads, Dh, Dh ** -0.5,
-                                causal=True, out=B["att"][:n].unsqueeze(0)).squeeze(0)
+                                causal=True, out=B["att"][:n].unsqueeze(0), q_prescaled=True).squeeze(0)
             ops.gemm(att, L["wo"], None, residual=h, out=h2)
             x = ops.rmsnorm(h2, L["ln2"], c.eps, out=B["x"][:n])
             m = ops.gemm(x, L["wgu"], None, epilogue="swiglu", out=B["m"][:n])
@@ -160,12 +187,15 @@ class Qwen2Model:
 
 def splice_image_embeddings(ids, embed_table, image_features, max_len=None, labels=None):
     """llava_arch.py:208-343 for one sequence: text ids -> embedding rows, every -200 sentinel replaced by the next tensor of
-    `image_features`; zero sentinels => the visual tokens are dropped (:247-254, Q18); truncated to max_len (:288-291)."""
+    `image_features`; zero sentinels => the visual tokens are dropped (:247-254, Q18); truncated to max_len (:288-291).
+    An entry of `image_features` may also be a LIST of tensors ([short | retrieved ...] pieces of one image block): the pieces are copied
+    straight into the spliced sequence, which is what the reference's `torch.cat([short, long])` (inference_streaming_longva_v2.py:
+    188-196) followed by this splice produces, without materialising the concatenation first."""
     dev = embed_table.device
     ids = ids.to(dev)
     pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
-    feats = [f.reshape(-1, f.shape[-1]) for f in (image_features or [])]
-    n_img_rows = sum(feats[i].shape[0] for i in range(len(pos)))
+    feats = [[p.reshape(-1, p.shape[-1]) for p in f] if isinstance(f, (list, tuple)) else [f.reshape(-1, f.shape[-1])] for f in (image_features or [])]
+    n_img_rows = sum(p.shape[0] for i in range(len(pos)) for p in feats[i])
     total = ids.numel() - len(pos) + n_img_rows
     out = torch.empty((total, embed_table.shape[1]), dtype=torch.float16, device=dev)
     labels_out = torch.full((total,), IGNORE_INDEX, dtype=torch.long, device=dev)
@@ -179,12 +209,22 @@ def splice_image_embeddings(ids, embed_table, image_features, max_len=None, labe
         dst += seg
         src = p + 1
         if k < len(pos):
-            f = feats[k].to(dev, torch.float16)
-            out[dst:dst + f.shape[0]] = f
-            dst += f.shape[0]
+            for f in feats[k]:
+                out[dst:dst + f.shape[0]] = f          # (copy_ converts device / dtype where a caller hands over something else)
+                dst += f.shape[0]
     if max_len is not None:
         out, labels_out = out[:max_len], labels_out[:max_len]
     return out, labels_out
+
+
+def decode_nsplit(head_dim: int, cache_len: int) -> int:
+    """split-KV factor of a batch-1 decode step (shared by the eager step and the captured graph, so that both sum the partials in the same
+    order).  k_attn_decode (Dh = 128): one workgroup of four streaming waves per (KV head, split), ~6 chunks of 32 rows per wave: 64 splits x
+    4 KV heads = one workgroup per CU at a 49 k context (measured 32 / 64 / 128 splits: 290 / 309 / 301 tok/s, profiles/r03_run5).  Other
+    head dims (k_attn, one computing wave per workgroup): ~6 tiles of 64 rows per workgroup, up to 128 splits."""
+    if head_dim == 128:
+        return max(2, min(64, ((cache_len + 31) // 32) // 24))
+    return max(1, min(128, ((cache_len + 63) // 64) // 6))
 
 
 def _decode_one(self, embeds):
@@ -194,18 +234,20 @@ def _decode_one(self, embeds):
     pos0, S = self.cache_len, self.cache_len + 1
     dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
     h = embeds.reshape(1, -1)
-    nsplit = max(1, min(128, ((S + 63) // 64) // 2))
+    nsplit = decode_nsplit(Dh, pos0)
+    tq, tk = self.rope_tabs(S)
     for l, L in enumerate(self.L):
-        q = ops.gemv(L["wq"], h, L["bq"], rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)           # RMSNorm fused into the projections
-        kv = self.cache[l][pos0:S]
-        ops.gemv(L["wkv"], h, L["bkv"], out=kv, rms_gamma=L["ln1"], rms_eps=c.eps)
-        ops.rope_(q, c.heads, Dh, c.rope_theta, pos0)
-        ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, pos0)
+        # RMSNorm fused into the projections; fp32 sums -> RoPE with the fp32 tables -> ONE rounding (q pre-scaled): the arithmetic of
+        # k_decode_qkv<true> (the captured graph's single launch) in three launches
+        q32 = ops.gemv(L["wq"], h, L["bq"], out_f32=True, rms_gamma=L["ln1"], rms_eps=c.eps).view(1, dq)
+        kv32 = ops.gemv(L["wkv"], h, L["bkv"], out_f32=True, rms_gamma=L["ln1"], rms_eps=c.eps).view(1, 2 * dkv)
+        q = ops.rope_f32in(q32, tq, c.heads, Dh, torch.empty((1, dq), dtype=torch.float16, device=self.device), 0, pos0)
+        ops.rope_f32in(kv32, tk, c.kv_heads, Dh, self.cache[l][pos0:S], dkv, pos0)
         ck = self.cache[l][:S]
         # the G heads of a KV group become G query ROWS of that KV head purely by addressing (row stride Dh, head stride G*Dh)
         qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
         att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
-                            nsplit=nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(1, dq)
+                            nsplit=nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh, q_prescaled=True).view(1, dq)
         h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
         m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
         h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
@@ -273,8 +315,8 @@ class DecodeGraph:
     def __init__(self, lm, max_new_tokens=1024, nsplit=None, temperature=0.0, sampling=None):
         self.sampling = sampling if sampling is not None else Sampling(float(temperature))
         self.temperature = self.sampling.temperature    # > 0: sample; the uniform draw is a graph-safe torch.rand inside the graph
-        # split-KV factor: ~6 KV tiles per workgroup (49 k context: 128 splits = 2 workgroups per CU; measured 64: 243.5, 128: 247.9 tok/s)
-        self.lm, self.nsplit = lm, (nsplit if nsplit else max(1, min(128, ((lm.cache_len + 63) // 64) // 6)))
+        self.nsplit = nsplit if nsplit else decode_nsplit(lm.cfg.head_dim, lm.cache_len)
+        self.lm = lm
         dev = lm.device
         self.tok = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -293,10 +335,11 @@ class DecodeGraph:
         self.ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(1), 256), dtype=torch.uint8, device=dev)
         self.nxt = torch.zeros(1, dtype=torch.int64, device=dev)
         self.q_buf = torch.empty(c.heads * c.head_dim, dtype=torch.float16, device=dev)
+        self.tab_q, self.tab_k = lm.rope_tabs(lm.cache[0].shape[0] if lm.cache is not None else None)      # fp32 rotary tables the graph reads by pointer
         self._captured_ptrs = None
 
     def _ptrs(self):
-        return tuple(c.data_ptr() for c in self.lm.cache) + (self.lm.cache[0].shape[0],)
+        return tuple(c.data_ptr() for c in self.lm.cache) + (self.lm.cache[0].shape[0], self.tab_q.data_ptr(), self.tab_k.data_ptr())
 
     def valid(self):
         """False once the KV cache was reallocated after capture (reset_cache with a larger max_seq): the graph would replay into
@@ -309,12 +352,13 @@ class DecodeGraph:
         h = ops.gather_rows(self.tok, lm.embed)
         for l, L in enumerate(lm.L):
             # q / k / v projections + RMSNorm + RoPE + KV-cache append at row `pos`: one launch (gemv.hip k_decode_qkv)
-            q = ops.decode_qkv(L["wq"], L["wkv"], L["bq"], L["bkv"], h, L["ln1"], c.eps, self.q_buf, lm.cache[l], self.pos, c.heads, c.kv_heads, Dh,
-                               c.rope_theta).view(1, dq)
+            q = ops.decode_qkv_tab(L["wq"], L["wkv"], L["bq"], L["bkv"], h, L["ln1"], c.eps, self.q_buf, lm.cache[l], self.pos, c.heads, c.kv_heads, Dh,
+                                   self.tab_q, self.tab_k).view(1, dq)
             ck = lm.cache[l]
             qv = q.as_strided((1, G, Dh), (dq, Dh, 1))
             att = ops.attention(qv, ck[:, :dkv].unsqueeze(0), ck[:, dkv:].unsqueeze(0), c.kv_heads, c.kv_heads, Dh, Dh ** -0.5, causal=False,
-                                kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh, ws=self.ws_attn).view(1, dq)
+                                kv_len=self.len, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh, ws=self.ws_attn,
+                                q_prescaled=True).view(1, dq)
             h2 = ops.gemv(L["wo"], att, None, residual=h).view(1, -1)
             m = ops.gemv(L["wgu"], h2, None, epilogue="swiglu", rms_gamma=L["ln2"], rms_eps=c.eps)
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
@@ -403,6 +447,7 @@ class BatchDecoder:
         self.lm, self.B = lm, len(prompts)
         self.cap = max(int(e.shape[0]) for e in prompts) + max_new_tokens
         dev = lm.device
+        lm.rope_tabs(self.cap)                                   # rotary tables cover every position of this batch before a step is captured
         self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self._ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
@@ -427,17 +472,16 @@ class BatchDecoder:
         kvlen = self.len + 1
         for l, L in enumerate(lm.L):
             x = ops.rmsnorm(h, L["ln1"], c.eps)
-            q = ops.gemm(x, L["wq"], L["bq"])
-            kv = ops.gemm(x, L["wkv"], L["bkv"])
-            ops.rope_(q, c.heads, Dh, c.rope_theta, positions=self.len)
-            ops.rope_(kv, c.kv_heads, Dh, c.rope_theta, positions=self.len)     # K = columns [0, dkv)
+            q = torch.empty((B, dq), dtype=torch.float16, device=h.device)
+            kv = torch.empty((B, 2 * dkv), dtype=torch.float16, device=h.device)
+            lm._qkv_rows(x, L, 0, q, kv, positions=self.len)                    # fp32 sums -> RoPE at each sequence's position -> one rounding
             ck = self.cache[l]
             ck.view(B * self.cap, -1).index_copy_(0, rows, kv)
             # the G query heads of a KV group as G query ROWS of that KV head (addressing only; q batch stride = dq)
             G = c.heads // c.kv_heads
             att = ops.attention(q.as_strided((B, G, Dh), (dq, Dh, 1)), ck[:, :, :dkv], ck[:, :, dkv:], c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,
                                 causal=False, kv_len=kvlen, nsplit=self.nsplit, q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh,
-                                ws=self._ws_attn).view(B, dq)
+                                ws=self._ws_attn, q_prescaled=True).view(B, dq)
             h2 = ops.gemm(att, L["wo"], None, residual=h)
             m = ops.gemm(ops.rmsnorm(h2, L["ln2"], c.eps), L["wgu"], None, epilogue="swiglu")
             h = ops.gemm(m, L["wd"], None, residual=h2)

@@ -346,6 +346,65 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
+def gemm_headed_ok(N: int, K: int, *tensors) -> bool:
+    """shapes sc_gemm_headed_f16 serves (the hand-scheduled kernel): anything else takes gemm(out_f32=True) + rope_f32in / a plain scale"""
+    return N % 256 == 0 and K % 128 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def gemm_headed(a, w, bias, out, mode: str, lead_cols: int, rope_tab=None, pos0: int = 0, col_scale: float = 1.0):
+    """out[M,N] = headed_epilogue(a @ w^T + bias), fp16 out.  mode "rope": columns [0, lead_cols) are rotary heads of width 128 rotated with
+    rows pos0.. of the fp32 table `rope_tab` (one rounding); mode "colscale": columns < lead_cols scaled by col_scale.  Only where
+    gemm_headed_ok() holds."""
+    _require_cuda(a, w, out)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if a.dtype != torch.float16 or w.dtype != torch.float16 or out.dtype != torch.float16 or a.stride(1) != 1 or out.stride(1) != 1 or not w.is_contiguous():
+        raise StreamChatHipError("gemm_headed: fp16 row-major operands only")
+    from ctypes import c_void_p
+    P = lambda t: None if t is None else c_void_p(t.data_ptr())
+    with torch.cuda.device(a.device), _timed("k_gemm", 2.0 * M * N * K):
+        check(lib.sc_gemm_headed_f16(P(a), a.stride(0), P(w), P(bias), P(out), out.stride(0), M, N, K, {"rope": 4, "colscale": 5}[mode], P(rope_tab), int(pos0),
+                                     int(lead_cols), c_float(col_scale), stream_ptr(a.device)), "sc_gemm_headed_f16")
+    return out
+
+
+_rope_tables = {}
+
+
+def rope_table(max_pos: int, Dh: int, theta: float, scale: float, device) -> torch.Tensor:
+    """fp32 [>= max_pos, 2, Dh/2] (cos | sin) * scale, built once per (device, Dh, theta, scale) and grown in powers of two."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), Dh, float(theta), float(scale))
+    t = _rope_tables.get(key)
+    if t is None or t.shape[0] < max_pos:
+        n = 1 << max(12, (int(max_pos) - 1).bit_length())
+        t = torch.empty((n, 2, Dh // 2), dtype=torch.float32, device=dev)
+        from ctypes import c_void_p
+        with torch.cuda.device(dev):
+            check(_lib.load().sc_rope_table_f32(c_void_p(t.data_ptr()), n, Dh, c_float(theta), c_float(scale), stream_ptr(dev)), "sc_rope_table_f32")
+        _rope_tables[key] = t
+    return t
+
+
+def rope_f32in(x32, tab, heads: int, Dh: int, out, plain_cols: int = 0, pos0: int = 0, positions=None):
+    """x32 [rows, >= heads*Dh + plain_cols] fp32 (projection + bias) -> out fp16: `heads` rotary heads rotated with the table (one rounding), then
+    `plain_cols` columns cast unchanged."""
+    _require_cuda(x32, tab, out)
+    if x32.dtype != torch.float32 or out.dtype != torch.float16 or x32.stride(-1) != 1 or out.stride(-1) != 1:
+        raise StreamChatHipError("rope_f32in: fp32 in, fp16 out, unit last stride")
+    x2, o2 = x32.reshape(-1, x32.shape[-1]) if x32.dim() == 1 else x32, out.reshape(-1, out.shape[-1]) if out.dim() == 1 else out
+    pos = None if positions is None else positions.to(device=x32.device, dtype=torch.int32).contiguous()
+    from ctypes import c_void_p
+    with torch.cuda.device(x32.device):
+        check(_lib.load().sc_rope_f32in_f16(c_void_p(x2.data_ptr()), x2.stride(0), c_void_p(tab.data_ptr()), ptr(pos), int(pos0), x2.shape[0], heads, Dh, plain_cols,
+                                            c_void_p(o2.data_ptr()), o2.stride(0), stream_ptr(x32.device)), "sc_rope_f32in_f16")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out=None):
     _require_cuda(x, gamma, beta)
     lib = _lib.load()
@@ -377,14 +436,15 @@ def attention_workspace_bytes(B: int, Hq: int, Sq: int, nsplit: int, Dh: int) ->
 
 
 def attention_variant(Dh: int, Sq: int, nsplit: int = 1) -> int:
-    """Kernel sc_attention_f16 dispatches for this shape in this process (0 k_attn, 1 k_attn long-prefill variant, 2 k_attn_fat)."""
+    """Kernel sc_attention_f16 dispatches for this shape in this process (0 k_attn, 1 k_attn long-prefill variant, 2 k_attn_fat, 3 k_attn_decode for non-causal calls)."""
     return int(_lib.load().sc_attention_variant(Dh, Sq, nsplit))
 
 
 def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = False, kv_len=None, out=None, nsplit: int = 1,
-              q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None, ws=None):
+              q_head_stride: int = 0, o_head_stride: int = 0, out_ld=None, ws=None, q_prescaled: bool = False):
     """Fused attention.  q [B, Sq, >=Hq*Dh], k/v [B, Skv, >=Hkv*Dh] fp16 (may be strided column slices of one fused
-    QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh]."""
+    QKV buffer: only stride(-1) == 1 and a common row stride per tensor are required).  Returns [B, Sq, Hq*Dh].
+    q_prescaled: q already carries scale * log2(e) from its producer (gemm_headed, decode_qkv_tab, rope_f32in with a scaled table)."""
     _require_cuda(q, k, v)
     lib = _lib.load()
     B, Sq = q.shape[0], q.shape[1]
@@ -408,7 +468,7 @@ def attention(q, k, v, Hq: int, Hkv: int, Dh: int, scale: float, causal: bool = 
         ws = None
     with torch.cuda.device(q.device), _timed("k_attn", 4.0 * B * Hq * Sq * Skv * Dh * (0.5 if causal else 1.0)):
         check(lib.sc_attention_f16(P(q), q.stride(1), P(k), k.stride(1), P(v), v.stride(1), P(out), ldo, B, Sq, Skv, Hq, Hkv, Dh,
-                                   c_float(scale), 1 if causal else 0, P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel() * ws.element_size()),
+                                   c_float(scale), (1 if causal else 0) | (2 if q_prescaled else 0), P(kl), nsplit, P(ws), c_size_t(0 if ws is None else ws.numel() * ws.element_size()),
                                    q_head_stride, o_head_stride, c_int64(q.stride(0) if B > 1 else 0), c_int64(out.stride(0) if B > 1 else 0),
                                    stream_ptr(q.device)), "sc_attention_f16")
     return out
@@ -551,6 +611,19 @@ def decode_qkv(wq, wkv, bq, bkv, x, rms_gamma, rms_eps: float, q_out, cache, row
         check(lib.sc_decode_qkv_f16(ptr(wq), ptr(wkv), ptr(bq), ptr(bkv), ptr(x.reshape(-1)), ptr(rms_gamma), c_float(rms_eps), c_void_p(q_out.data_ptr()),
                                     c_void_p(cache.data_ptr()), cache.stride(0), ptr(row_index), q_heads, kv_heads, Dh, wq.shape[1], c_float(theta),
                                     stream_ptr(x.device)), "sc_decode_qkv_f16")
+    return q_out
+
+
+def decode_qkv_tab(wq, wkv, bq, bkv, x, rms_gamma, rms_eps: float, q_out, cache, row_index, q_heads: int, kv_heads: int, Dh: int, tab_q, tab_k):
+    """decode_qkv with the one-rounding rotary arithmetic of the prefill GEMM epilogue: RoPE of the fp32 sums with the fp32 tables (tab_q carries
+    the softmax scale * log2 e: q_out is pre-scaled), rounded once.  Bit-identical to gemv(out_f32) + rope_f32in."""
+    _require_cuda(wq, wkv, x, q_out, cache, row_index, tab_q, tab_k)
+    lib = _lib.load()
+    from ctypes import c_void_p
+    with torch.cuda.device(x.device), _timed("k_gemv", 2.0 * (wq.shape[0] + wkv.shape[0]) * wq.shape[1]):
+        check(lib.sc_decode_qkv_tab_f16(ptr(wq), ptr(wkv), ptr(bq), ptr(bkv), ptr(x.reshape(-1)), ptr(rms_gamma), c_float(rms_eps), c_void_p(q_out.data_ptr()),
+                                        c_void_p(cache.data_ptr()), cache.stride(0), ptr(row_index), q_heads, kv_heads, Dh, wq.shape[1],
+                                        c_void_p(tab_q.data_ptr()), c_void_p(tab_k.data_ptr()), stream_ptr(x.device)), "sc_decode_qkv_tab_f16")
     return q_out
 
 

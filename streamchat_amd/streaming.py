@@ -150,9 +150,10 @@ def longva_inference_with_embedding_multi_modal(question, num_frames, conv_mode,
     if long_memory_tree_cache is not None:
         long_memory_list, long_memory_text_list = U.fast_search_tree_multi_modal_with_embedding(
             long_memory_tree_cache, question, short_memory_embedding, embedding_model, embedding_tokenizer, cache=search_cache)
-        long_memory_embeddings = torch.cat([t.reshape(-1, t.shape[-1]) for t in long_memory_list], dim=0)
         most_fine_grad_text = long_memory_text_list[-1]
-        image_embeddings = torch.cat([short_memory_embedding, long_memory_embeddings], dim=0)
+        # upstream: torch.cat([short, torch.cat(long)]) (:188-196); the pieces are handed over as they are and the <image> splice writes them
+        # in this order into the prompt embeddings (llm.splice_image_embeddings) - same rows, one 350 MB copy less
+        image_embeddings = [short_memory_embedding] + [t.reshape(-1, t.shape[-1]) for t in long_memory_list]
     else:
         image_embeddings, most_fine_grad_text = short_memory_embedding, None
     qs = build_answer_prompt(question, most_fine_grad_text, history_prompt, getattr(model.config, "mm_use_im_start_end", False))

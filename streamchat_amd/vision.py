@@ -118,11 +118,18 @@ class CLIPVisionTower:
         pe = ops.gemm(B["patches"][: n * P], self.patch_w, out=B["pe"][: n * P])
         h = ops.vit_embed_ln(pe, self.cls, self.pos, self.pre_g, self.pre_b, c.eps, n, P, out=B["h"][:M])
         h2 = B["h2"][:M]
+        # the q third of the fused q|k|v projection leaves the GEMM already multiplied by the softmax scale * log2 e (applied to the fp32
+        # sum, one rounding - HF's CLIPAttention scales q the same way) where the hand-scheduled kernel serves the shape; attention then
+        # runs without a per-score multiply (SC_ATTN_Q_PRESCALED)
+        pre = ops.gemm_headed_ok(3 * D, D, B["x"], B["qkv"], self.L[0]["wqkv"], self.L[0]["bqkv"]) if self.L else False
         for L in self.L:
             x = ops.layernorm(h, L["ln1"][0], L["ln1"][1], c.eps, out=B["x"][:M])
-            qkv = ops.gemm(x, L["wqkv"], L["bqkv"], out=B["qkv"][:M]).view(n, S, 3 * D)
+            if pre:
+                qkv = ops.gemm_headed(x, L["wqkv"], L["bqkv"], B["qkv"][:M], "colscale", D, col_scale=0.125 * ops.LOG2E).view(n, S, 3 * D)
+            else:
+                qkv = ops.gemm(x, L["wqkv"], L["bqkv"], out=B["qkv"][:M]).view(n, S, 3 * D)
             att = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], c.heads, c.heads, 64, 0.125,
-                                out=B["att"][:M].view(n, S, D)).view(M, D)
+                                out=B["att"][:M].view(n, S, D), q_prescaled=pre).view(M, D)
             ops.gemm(att, L["wo"], L["bo"], residual=h, out=h2)
             x = ops.layernorm(h2, L["ln2"][0], L["ln2"][1], c.eps, out=B["x"][:M])
             f = ops.gemm(x, L["w1"], L["b1"], epilogue="quick_gelu", out=B["f"][:M])

@@ -203,7 +203,7 @@ def test_c2_tree_and_retrieved_frames_identical(c2):
 
 def test_c2_merged_centroids_close(c2):
     """the merged node's 5 centroid frames: HIP (fp16 features, fp32 means) vs CPU (fp32 features): same clusters, feature rounding apart"""
-    from _tol import assert_close_fp16
+    from tests._tol import assert_close_fp16
     hip_feats, ref = c2["feats"].float().cpu(), c2["ref"]
     labels = c2["cpu"]["labels"]
     for k in range(5):

@@ -199,40 +199,6 @@ def test_attention_randomised_shapes_and_padding():
         torch.testing.assert_close(out.float()[ok], ref[ok], rtol=3e-3, atol=3e-3, msg=lambda m: f"case {case}: Dh={Dh} B={B} Sq={Sq} Skv={Skv} Hq={Hq} Hkv={Hkv} causal={causal} kv_len={None if kv_len is None else kv_len.tolist()}\n{m}")
 
 
-def test_attention_hand_scheduled_long_prefill_kernel_opt_in():
-    """SC_ATTN_FAT=1 routes Dh = 128 / Sq >= 2048 / unsplit attention to k_attn_fat (attention_fat.hip: one wave per SIMD, asm-scheduled
-    v_mfma_f32_32x32x16_f16 loop, masked-tile body, exact redo pass).  The switch is read once per process, so the long-prefill cases
-    and the late-huge-score case run again in a child process with the switch on; the child asserts that variant 2 is what runs."""
-    import subprocess
-    import sys
-    assert ops.attention_variant(128, 4096) in (1, 2) and ops.attention_variant(64, 4096) == 0 and ops.attention_variant(128, 4096, 4) == 0
-    code = ("import tests.test_gpu_dense as T\n"
-            "from streamchat_amd import ops\n"
-            "assert ops.attention_variant(128, 2048) == 2 and ops.attention_variant(128, 2047) == 0\n"
-            "for a in [(1, 2304, 2304, 4, 2, True, False), (2, 2050, 2500, 2, 2, False, True), (1, 2048, 3000, 7, 1, True, False), (1, 4100, 4100, 2, 1, True, False)]:\n"
-            "    T.test_attention_long_dh128_three_qblock_path(*a)\n"
-            "T.test_attention_late_huge_score_forces_the_exact_pass(128, True)\n"
-            "import random, torch\n"
-            "rnd = random.Random(7)\n"
-            "for case in range(10):\n"
-            "    B, Hkv = rnd.choice([1, 2]), rnd.choice([1, 2])\n"
-            "    Hq, causal = Hkv * rnd.choice([1, 3]), rnd.random() < 0.6\n"
-            "    Sq = rnd.randint(2048, 2500); Skv = Sq + rnd.choice([0, 0, 37, 700])\n"
-            "    q, k, v = T._rand((B, Sq, Hq * 128), 100 + case), T._rand((B, Skv, Hkv * 128), 200 + case), T._rand((B, Skv, Hkv * 128), 300 + case)\n"
-            "    k[:, Skv - 50:] = float('nan'); v[:, Skv - 50:] = float('nan')             # allocator garbage behind the valid rows\n"
-            "    kv_len = torch.tensor([rnd.choice([Skv - 50, Skv - 64, Skv - 113, 65, 64, 1]) for _ in range(B)], device='cuda', dtype=torch.int32)\n"
-            "    if causal: kv_len = torch.clamp(kv_len, min=Skv - 113)                       # causal: every query must keep a visible key\n"
-            "    out = ops.attention(q, k, v, Hq, Hkv, 128, 0.09, causal, kv_len)\n"
-            "    kk, vv = k.clone(), v.clone(); kk[:, Skv - 50:] = 0; vv[:, Skv - 50:] = 0\n"
-            "    ref = T._attn_ref(q, kk, vv, Hq, Hkv, 128, 0.09, causal, kv_len)\n"
-            "    ok = torch.isfinite(ref).all(-1)                                             # rows without any visible key are undefined in the reference\n"
-            "    torch.testing.assert_close(out.float()[ok], ref[ok], rtol=2e-3, atol=2e-3)\n"
-            "print('fat ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SC_ATTN_FAT": "1"}, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "fat ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 @pytest.mark.parametrize("N,K", [(3584, 3584), (1024, 3584), (152064, 3584), (3584, 18944), (130, 264)])
 def test_gemv_vs_torch_fp32(N, K):
     w, x, b, r = _rand((N, K), 1, K ** -0.5), _rand((K,), 2), _rand((N,), 3), _rand((N,), 4)
@@ -259,6 +225,52 @@ def test_attention_split_kv_equals_unsplit(Sq, Skv, H, Dh, ns):
     a = ops.attention(q, k, v, H, H, Dh, Dh ** -0.5, False, nsplit=ns)
     ref = _attn_ref(q, k, v, H, H, Dh, Dh ** -0.5, False)
     torch.testing.assert_close(a.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_attention_decode_streaming_kernel_randomised():
+    """Dh = 128, <= 16 query rows, split-KV, non-causal = a decode step: k_attn_decode (every wave streams its own run of 32-row chunks, K
+    straight into MFMA operands, V through a per-wave LDS ring, in-block merge of the four waves, then k_attn_combine).  Seeded sweep
+    over key counts around the chunk / split / wave boundaries (fewer chunks than waves, empty splits), split factors, batches with
+    per-sequence lengths, GQA groups and NaN garbage behind the valid keys; against fp32 torch."""
+    import random
+    rnd = random.Random(5)
+    assert ops.attention_variant(128, 7, 16) == 3 and ops.attention_variant(128, 17, 16) == 0 and ops.attention_variant(64, 7, 16) == 0
+    for case in range(24):
+        B, Hkv = rnd.choice([1, 1, 2, 3]), rnd.choice([1, 2, 4])
+        Hq = Hkv * rnd.choice([1, 1, 2])
+        Sq = rnd.choice([1, 2, 7, 8, 15, 16])
+        Skv = rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 1000, 4097, rnd.randint(1, 9000)])
+        ns = rnd.choice([2, 3, 7, 16, 64, 128])
+        q, k, v = _rand((B, Sq, Hq * 128), 900 + case), _rand((B, Skv, Hkv * 128), 1000 + case), _rand((B, Skv, Hkv * 128), 1100 + case)
+        kv_len, kk, vv = None, k.clone(), v.clone()
+        if rnd.random() < 0.6:
+            lens = [max(1, min(Skv, rnd.choice([Skv, Skv - 1, Skv - 31, Skv - 32, Skv - 33, 1, 32, 33, Skv // 2]))) for _ in range(B)]
+            kv_len = torch.tensor(lens, device="cuda", dtype=torch.int32)
+            for b in range(B):
+                k[b, lens[b]:] = float("nan"); v[b, lens[b]:] = float("nan"); kk[b, lens[b]:] = 0; vv[b, lens[b]:] = 0
+        out = ops.attention(q, k, v, Hq, Hkv, 128, 0.09, False, kv_len, nsplit=ns)
+        ref = _attn_ref(q, kk, vv, Hq, Hkv, 128, 0.09, False, kv_len)
+        assert torch.isfinite(out.float()).all(), (case, B, Sq, Skv, Hq, Hkv, ns)
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3, msg=lambda m: f"case {case}: B={B} Sq={Sq} Skv={Skv} Hq={Hq} Hkv={Hkv} ns={ns} kv_len={None if kv_len is None else kv_len.tolist()}\n{m}")
+
+
+def test_attention_decode_streaming_kernel_long_context_packed_heads():
+    """the call llm._decode_one / DecodeGraph make: the G = 7 query heads of a KV group as 7 query ROWS of that KV head (addressing only),
+    49 157 keys in a cache with capacity beyond them, 128 splits"""
+    S, cap, G, Hkv, Dh = 49157, 49152 + 64, 7, 4, 128
+    q = _rand((1, G * Hkv * Dh), 1)
+    cache = _rand((cap, 2 * Hkv * Dh), 2, 0.5)
+    cache[S:] = float("nan")
+    ck = cache[:cap]
+    kl = torch.tensor([S], device="cuda", dtype=torch.int32)
+    qv = q.as_strided((1, G, Dh), (G * Hkv * Dh, Dh, 1))
+    out = ops.attention(qv, ck[:, :Hkv * Dh].unsqueeze(0), ck[:, Hkv * Dh:].unsqueeze(0), Hkv, Hkv, Dh, Dh ** -0.5, causal=False, kv_len=kl, nsplit=128,
+                        q_head_stride=G * Dh, o_head_stride=G * Dh, out_ld=Dh).view(Hkv, G, Dh)
+    kf, vf = cache[:S, :Hkv * Dh].float().view(S, Hkv, Dh), cache[:S, Hkv * Dh:].float().view(S, Hkv, Dh)
+    qf = q.float().view(Hkv, G, Dh)
+    p = torch.softmax(torch.einsum("hgd,shd->hgs", qf, kf) * Dh ** -0.5, -1)
+    ref = torch.einsum("hgs,shd->hgd", p, vf)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(5000, 4096, 1024, "quick_gelu"), (9000, 2048, 192, "none"), (4099, 8192, 512, "swiglu"), (16640, 1024, 4096, "gelu")])

@@ -67,6 +67,11 @@ def test_splice_matches_reference():
         out, _ = LM.splice_image_embeddings(torch.from_numpy(d[k + ".ids"]), table, [feats], None if mx < 0 else mx)
         ref = torch.from_numpy(d[k + ".embeds"]).cuda().half()          # fp16 rounding of the fp32 golden rows is exact data movement
         assert torch.equal(out, ref), k
+        # the image block handed over as [short | retrieved ...] pieces (views of the feature bank) splices to the same rows as their cat
+        n = feats.shape[0]
+        pieces = [feats[:1], feats[1:n // 2], feats[n // 2:]]
+        out2, _ = LM.splice_image_embeddings(torch.from_numpy(d[k + ".ids"]), table, [pieces], None if mx < 0 else mx)
+        assert torch.equal(out2, ref), k
 
 
 def test_rope_and_swiglu_kernels_vs_torch():

@@ -75,7 +75,8 @@ def test_answer_prompt_branches_match_reference(monkeypatch):
         config = types.SimpleNamespace(mm_use_im_start_end=False)
 
         def generate_with_image_embedding(self, input_ids, image_embeddings=None, **kw):
-            captured.update(input_ids=input_ids[0].tolist(), emb=image_embeddings[0].clone(), kw=kw)
+            e = image_embeddings[0]                  # one image block: a tensor, or its [short | retrieved ...] pieces in order (spliced without a cat)
+            captured.update(input_ids=input_ids[0].tolist(), emb=torch.cat(list(e)) if isinstance(e, (list, tuple)) else e.clone(), kw=kw)
             return torch.tensor([[1, 2, 3]])
 
     def fake_search(tree, question, short, emb_model, emb_tok, **kw):

@@ -1,15 +1,11 @@
 #!/usr/bin/env python3
 """Sustained launches of one hot kernel while sampling the package power and the shader clock (rocm-smi): shows which kernels sit on
-the board's power cap.  usage: python tools/power_probe.py attn49k|attn49k_fat|gemm_llm|gemm_llm_8wave|gemm_vit|vit_attn|decode|idle [seconds]"""
+the board's power cap.  usage: python tools/power_probe.py attn49k|gemm_llm|gemm_llm_8wave|gemm_vit|vit_attn|decode|idle [seconds]"""
 import os, subprocess, sys, threading, time
 what = sys.argv[1] if len(sys.argv) > 1 else "attn49k"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
-if what == "attn49k_fat":
-    os.environ["SC_ATTN_FAT"] = "1"
-elif what == "gemm_llm_8wave":
+if what == "gemm_llm_8wave":
     os.environ["SC_GEMM_FAT"] = "0"           # the 8-wave k_gemm256 instead of the hand-scheduled 4-wave k_gemm_fat
-elif what == "attn49k":
-    os.environ["SC_ATTN_FAT"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from streamchat_amd import ops
