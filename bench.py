@@ -39,7 +39,7 @@ MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 
 
 def parse():
@@ -435,8 +435,8 @@ def relaunch_one_rank_per_gpu(n):
 
 def main():
     a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(relaunch_one_rank_per_gpu(a.gpus))
+    if a.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        sys.exit(relaunch_one_rank_per_gpu(a.gpus))       # not under a launcher (no LOCAL_RANK) and no N-rank job around us: start the ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
