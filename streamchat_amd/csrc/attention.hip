@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     // Row sums on the matrix pipe at head dim <= 64: one extra MFMA per (q-block, 32 kv rows) with an all-ones A operand gives
     // sum_kv P[kv][q] in every row of a 16 x 16 accumulator (the fp16-rounded P, exactly what P.V uses; complete over the four lane
     // groups, so no shuffles at the end).  At Dh = 64 the loop is bound by the VALU port (2.8 VALU per MFMA, the pipe 25-40 % busy):
-    // this trades 8 v_add per lane and chunk for half an MFMA.  At Dh = 128 the pipe (and the board's power) is the limit: VALU adds stay.
-    constexpr bool LSUM_MFMA = (DH <= 64);
+    // this trades 8 v_add per lane and chunk for half an MFMA.  At Dh = 128 the pipe (and the board's power) was the limit and the VALU adds
+    // stayed - until the pre-scaled-q mode took the FMA out of the loop: with it the adds are the next VALU instructions to go and the ones-MFMA
+    // wins there too (+1 % at 49 k: 1262 -> 1274 TF, profiles/r03_run9), so PRE takes the matrix-pipe row sums at every head dim.
+    constexpr bool LSUM_MFMA = (DH <= 64) || PRE;
     sc_f4 ol[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) ol[qb] = sc_f4{0.f, 0.f, 0.f, 0.f};

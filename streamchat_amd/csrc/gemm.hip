@@ -813,6 +813,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                         const float a = acc[mi][nj][e] + ba[e], b = acc[mi][nj + 4][e] + bb[e];
                         oa[e] = __builtin_fmaf(-b, s4[e], a * c4[e]);
                         ob[e] = __builtin_fmaf(a, s4[e], b * c4[e]);
+                        asm volatile("" : "+v"(oa[e]), "+v"(ob[e]));      // fp32 fma, THEN the fp16 rounding: never one v_fma_mix (see k_decode_qkv)
                     }
                     (h ? ha : la)[0] = pack2(oa[0], oa[1]); (h ? ha : la)[1] = pack2(oa[2], oa[3]);
                     (h ? hb : lb)[0] = pack2(ob[0], ob[1]); (h ? hb : lb)[1] = pack2(ob[2], ob[3]);

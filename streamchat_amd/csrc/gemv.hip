@@ -5,6 +5,7 @@
 // each of its 4 weight rows (1 KiB coalesced per row), accumulates with v_dot2_f32_f16, and finishes with a wave reduction.
 // No LDS: the operand is streamed once per block and never shared (cdna guide §5 "GEMV / M <= 16" row).
 #include "sc_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -16,19 +17,24 @@ namespace {
 // the fused norm).  Shared by k_gemv<NORM> and k_decode_qkv so that the eager decode step and the captured graph stay bit-identical.
 __device__ __forceinline__ void block_rmsnorm_to_lds(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma, int K, float eps, _Float16* xn,
                                                      float* red) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float ss = 0.f;
-    for (int k = t * 8; k < K; k += 2048) {
-        const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
+    // The reduction order is that of 256 VIRTUAL threads whatever the workgroup size (2, 3 or 4 waves: the launchers pick the wave count
+    // that deals the rows evenly over the CUs): virtual thread v sums the 8-element chunks v, v + 256, ...; a virtual wave is reduced
+    // with the xor-shuffle tree; the four virtual-wave sums are added in order.
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    for (int vw = wave; vw < 4; vw += nw) {
+        float ss = 0.f;
+        for (int k = (vw * 64 + lane) * 8; k < K; k += 2048) {
+            const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+            for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        if (lane == 0) red[vw] = ss;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
-    if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float rstd = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
-    for (int k = t * 8; k < K; k += 2048) {
+    for (int k = t * 8; k < K; k += (int)blockDim.x * 8) {
         const sc_h8 xv = *reinterpret_cast<const sc_h8*>(x + k), gv = *reinterpret_cast<const sc_h8*>(gamma + k);
         sc_h8 o;
 #pragma unroll
@@ -39,14 +45,15 @@ __device__ __forceinline__ void block_rmsnorm_to_lds(const _Float16* __restrict_
 }
 
 template <bool SWIGLU, bool OUT_F32, int RPW, int UNR = 4>
-__global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
+__global__ __launch_bounds__(256) void k_gemv(      // 2 or 4 waves per workgroup (launcher's choice: whichever deals the rows evenly over the CUs)
+const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
                                               const _Float16* __restrict__ res, void* __restrict__ y_base, int N, int K,
                                               const int* __restrict__ y_row, int y_ld, const _Float16* __restrict__ gamma, float eps) {
     // optional dynamic output row (KV-cache append at a device-resident position: keeps a decode step hipGraph-replayable)
     void* y = y_row ? (void*)(reinterpret_cast<_Float16*>(y_base) + (size_t)y_row[0] * (size_t)y_ld) : y_base;
     extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
     float acc[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
                                                     const float* __restrict__ tab_q, const float* __restrict__ tab_k) {
     const int lane = threadIdx.x & 63;
     const int half = Dh >> 1;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);                 // (head, j) over q heads, then k heads, then v heads
+    const int task = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);   // (head, j) over q heads, then k heads, then v heads
     const int ntask = (Hq + 2 * Hkv) * half;
     const bool live = task < ntask;                                       // (dead waves of the last workgroup still take part in the norm's barriers)
     const int hh = (live ? task : 0) / half, j = (live ? task : 0) - hh * half;
@@ -206,8 +213,13 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
             const float a32 = acc0 + (b0 ? (float)b0[0] : 0.f), b32 = acc1 + (b0 ? (float)b0[half] : 0.f);
             const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)row * (size_t)Dh;
             const float cs = t[j], sn = t[half + j];
-            dst[0] = (_Float16)__builtin_fmaf(-b32, sn, a32 * cs);
-            dst[half] = (_Float16)__builtin_fmaf(a32, sn, b32 * cs);
+            // fp32 fma FIRST, then the rounding to fp16 - as k_rope_f32in and the GEMM epilogue do it: left alone, hipcc fuses the two into
+            // v_fma_mixlo_f16 (ONE rounding of the exact product-sum), which differs from fma -> cvt in the last fp16 bit on ties and made the
+            // captured decode graph and the eager step disagree by one ulp in a K row every few tokens
+            float ra = __builtin_fmaf(-b32, sn, a32 * cs), rb = __builtin_fmaf(a32, sn, b32 * cs);
+            asm volatile("" : "+v"(ra), "+v"(rb));
+            dst[0] = (_Float16)ra;
+            dst[half] = (_Float16)rb;
             return;
         }
         const float inv_freq = exp2f(-log2_theta * (float)(2 * j) / (float)Dh);
@@ -221,6 +233,16 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
     }
 }
 
+// Waves per workgroup.  4 everywhere.  (Round 3 tried to pick 2 / 3 / 4 per launch so that the workgroups deal evenly over the 256 CUs -
+// 576 workgroups are 3 on some CUs and 2 on others - and LOST: 299 vs 307 tok/s, profiles/r03_run9; the dispatcher balances by itself and
+// smaller workgroups repeat the norm more often.  SC_GEMV_WPB=2|3|4 still pins another count for experiments: block_rmsnorm_to_lds gives
+// the same bits for any of them.)
+int pick_wpb(int) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SC_GEMV_WPB"); const int v = e ? atoi(e) : 0; forced = (v >= 2 && v <= 4) ? v : 4; }
+    return forced;
+}
+
 }  // namespace
 
 extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma, float rms_eps,
@@ -232,7 +254,8 @@ extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
-    hipLaunchKernelGGL(k_decode_qkv<false>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+    const int wpb = pick_wpb(ntask);
+    hipLaunchKernelGGL(k_decode_qkv<false>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
                        cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta), (const float*)nullptr, (const float*)nullptr);
     SC_CHECK_LAUNCH("sc_decode_qkv_f16");
@@ -248,7 +271,8 @@ extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_tab_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
-    hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+    const int wpb = pick_wpb(ntask);
+    hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
                        cache_ld, pos, q_heads, kv_heads, Dh, K, 0.f, tab_q, tab_k);
     SC_CHECK_LAUNCH("sc_decode_qkv_tab_f16");
@@ -275,12 +299,13 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     // the tuning knob only applies where a kernel for that row count is instantiated (fp16 output); the fp32-output path of a short
     // projection always runs one row per wave, and the grid is derived from the rows per wave of the kernel actually launched
     const int rpw = few ? (out_f32 ? 1 : rpw_few) : 4;
-    const dim3 grid((unsigned)((N + 4 * rpw - 1) / (4 * rpw))), block(256);
+    const int wpb = pick_wpb((N + rpw - 1) / rpw), wpb2 = pick_wpb((N + 1) / 2);
+    const dim3 grid((unsigned)((N + wpb * rpw - 1) / (wpb * rpw))), block(64 * wpb);
     if (few && !out_f32 && (rpw == 2 || rpw == 4 || (rpw_few == 1 && K >= 8192))) {
         // long rows (the down projection, K = 18 944): two rows per wave and 8 x 16 B per lane in flight per row stream the 136 MB at
         // 5.56 TB/s against 5.11 (profiles/r02_run18: A/B of rows-per-wave x unroll on a >1 GB weight cycle); short rows: 1 row, unroll 4
         if (rpw == 4) hipLaunchKernelGGL((k_gemv<false, false, 4>), grid, block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
-        else hipLaunchKernelGGL((k_gemv<false, false, 2, 8>), dim3((unsigned)((N + 7) / 8)), block, gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
+        else hipLaunchKernelGGL((k_gemv<false, false, 2, 8>), dim3((unsigned)((N + 2 * wpb2 - 1) / (2 * wpb2))), dim3(64 * wpb2), gsm, s, w, xx, b, r, y, N, K, y_row, y_ld, (const _Float16*)rms_gamma, rms_eps);
         SC_CHECK_LAUNCH("sc_gemv_f16");
         return SC_OK;
     }

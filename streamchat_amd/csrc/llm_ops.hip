@@ -154,8 +154,10 @@ __global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x,
         sc_h4 oa, ob;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            oa[e] = (_Float16)__builtin_fmaf(-b[e], sn[e], a[e] * cs[e]);
-            ob[e] = (_Float16)__builtin_fmaf(a[e], sn[e], b[e] * cs[e]);
+            float ra = __builtin_fmaf(-b[e], sn[e], a[e] * cs[e]), rb = __builtin_fmaf(a[e], sn[e], b[e] * cs[e]);
+            asm volatile("" : "+v"(ra), "+v"(rb));                  // fp32 fma, THEN the fp16 rounding: never one v_fma_mix (see k_decode_qkv, gemv.hip)
+            oa[e] = (_Float16)ra;
+            ob[e] = (_Float16)rb;
         }
         *reinterpret_cast<sc_h4*>(orow + h * Dh + i0) = oa;
         *reinterpret_cast<sc_h4*>(orow + h * Dh + half + i0) = ob;
