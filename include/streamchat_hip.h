@@ -42,7 +42,8 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *      + sc_pick_token_f32, sc_pick_token_workspace_bytes     (arg-max / temperature sampling on device)
  *      + sc_sample_token_f32, sc_sample_token_workspace_bytes (repetition penalty / top-k / top-p chain)
  *      + sc_attention_variant      (which attention kernel a shape is dispatched to)
- *      round 3: + sc_gemm_headed_f16 (rotary / column-scale GEMM epilogues), sc_rope_table_f32, sc_rope_f32in_f16, sc_decode_qkv_tab_f16;
+ *      round 3: + sc_gemm_headed_f16 (rotary / column-scale GEMM epilogues), sc_rope_table_f32, sc_rope_f32in_f16, sc_decode_qkv_tab_f16,
+ *               sc_decode_advance;
  *               sc_attention_f16's `causal` argument became a flag word (bit 1 = SC_ATTN_Q_PRESCALED; 0 / 1 mean what they meant)
  *      (these seven shipped in round 2 under version 2 by mistake; 3 is the first version that guarantees them)
  */
@@ -265,6 +266,11 @@ int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq, const voi
  *   temperature  > 0: sample from softmax(logits / temperature) by inverting the CDF at u[b] in [0, 1) (device floats the
  *                     caller draws, e.g. from a torch generator: the draw, not the kernel, carries the randomness).
  *   ws: sc_pick_token_workspace_bytes(B) bytes.  Two launches, no host synchronisation (hipGraph-capturable). */
+/* Bookkeeping of one batch-1 decode step in ONE launch (round 3, ABI 3; all pointers device scalars except `ring`): ring[ring_index[0]] =
+ * next_token[0]; token[0] = next_token[0]; ring_index, pos, kv_len, n_prev += 1.  Replaces six elementwise launches per replay of the
+ * captured decode graph (llm.DecodeGraph). */
+int sc_decode_advance(const int64_t* next_token, int64_t* ring, int64_t* ring_index, int32_t* token, int32_t* pos, int32_t* kv_len,
+                      int32_t* n_prev, sc_stream_t stream);
 size_t sc_pick_token_workspace_bytes(int B);
 int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out,
                       void* ws, size_t ws_bytes, sc_stream_t stream);

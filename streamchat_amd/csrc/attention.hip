@@ -429,6 +429,15 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
     const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
     const int q = row % Sq, bh = row / Sq, h = bh % Hq, b = bh / Hq;
     const float* pp = part + (size_t)row * nsplit * (DH + 2);
+    // NW groups of DH threads walk the partials in an interleaved order, 8 independent loads in flight each: with a single group the
+    // kernel was one dependent load chain per output element (7.9 us for 128 partials: latency, not bytes).  The first batch of every
+    // thread is requested BEFORE the split weights are computed (they only multiply it): the two load latencies overlap instead of adding.
+    constexpr int NW = 1024 / DH < 8 ? 1024 / DH : 8;
+    __shared__ float red[NW][DH];
+    const int d = threadIdx.x % DH, w = threadIdx.x / DH;
+    float v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v0[u] = (w + u * NW < nsplit) ? pp[(w + u * NW) * (DH + 2) + d] : 0.f;
     if (threadIdx.x < 64) {
         float M = -INFINITY;
         for (int i = threadIdx.x; i < nsplit; i += 64) M = fmaxf(M, pp[i * (DH + 2) + DH]);
@@ -446,13 +455,10 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
         if (threadIdx.x == 0) inv_den = den > 0.f ? 1.0f / den : 0.f;
     }
     __syncthreads();
-    // NW groups of DH threads walk the partials in an interleaved order, 8 independent loads in flight each: with a single group the
-    // kernel was one dependent load chain per output element (7.9 us for 128 partials: latency, not bytes)
-    constexpr int NW = 1024 / DH < 8 ? 1024 / DH : 8;
-    __shared__ float red[NW][DH];
-    const int d = threadIdx.x % DH, w = threadIdx.x / DH;
     float num = 0.f;
-    int i = w;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (w + u * NW < nsplit) num += v0[u] * wgt[w + u * NW];
+    int i = w + 8 * NW;
     for (; i + 7 * NW < nsplit; i += 8 * NW) {
         float v[8];
 #pragma unroll

@@ -63,6 +63,14 @@ const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* 
     // optional fused Qwen2 RMSNorm of x (gamma != NULL): the workgroup normalises x once into LDS (block_rmsnorm_to_lds) and the weight
     // stream below reads the finished vector; the first weight loads of every row are requested BEFORE that, so that the norm's
     // load -> reduce -> barrier chain runs under their latency instead of in front of it
+    // what the epilogue adds (bias, residual) is requested NOW: read at the end, these dependent scalar-sized loads were a full memory
+    // latency each on the tail of every wave of a 6 us kernel
+    float eb[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int n = row0 + r < N ? row0 + r : N - 1;
+        eb[r] = (SWIGLU || row0 >= N) ? 0.f : ((bias ? (float)bias[n] : 0.f) + (res ? (float)res[n] : 0.f));
+    }
     constexpr int PF = RPW >= 4 ? 2 : 4;                           // K-slices requested ahead of the norm
     _Float16* xn = reinterpret_cast<_Float16*>(gemv_smem);
     sc_h8 w0[PF][RPW];
@@ -125,7 +133,7 @@ const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* 
             for (int r = 0; r < RPW; ++r) {
                 const int n = row0 + r;
                 if (n < N) {
-                    float v = acc[r] + (bias ? (float)bias[n] : 0.f) + (res ? (float)res[n] : 0.f);
+                    float v = acc[r] + eb[r];
                     if (OUT_F32) reinterpret_cast<float*>(y)[n] = v;
                     else reinterpret_cast<_Float16*>(y)[n] = (_Float16)v;
                 }
@@ -161,6 +169,15 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
     else if (hh < Hq + Hkv) { kind = 1; h = hh - Hq; w0 = Wkv + (size_t)(h * Dh + j) * (size_t)K; b0 = bkv ? bkv + h * Dh + j : nullptr; }
     else { kind = 2; h = hh - Hq - Hkv; w0 = Wkv + (size_t)((Hkv + h) * Dh + j) * (size_t)K; b0 = bkv ? bkv + (Hkv + h) * Dh + j : nullptr; }
     const _Float16* w1 = w0 + (size_t)half * (size_t)K;
+    // everything the epilogue needs besides the two dot products is requested NOW (position, bias pair, table row): read at the end, these
+    // were four dependent memory latencies (~2 us) on the tail of every wave of a 10 us kernel
+    const int row = pos[0];
+    const float bias0 = (live && b0) ? (float)b0[0] : 0.f, bias1 = (live && b0) ? (float)b0[half] : 0.f;
+    float tcs = 1.f, tsn = 0.f;
+    if (TAB && live && kind != 2) {
+        const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)row * (size_t)Dh;
+        tcs = t[j]; tsn = t[half + j];
+    }
     // RMSNorm of x once per workgroup into LDS; the first four K-slices of both weight rows are requested before it (see k_gemv)
     extern __shared__ __attribute__((aligned(16))) char qkv_smem[];
     _Float16* xn = reinterpret_cast<_Float16*>(qkv_smem);
@@ -205,14 +222,11 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { acc0 += __shfl_xor(acc0, m, 64); acc1 += __shfl_xor(acc1, m, 64); }
     if (lane == 0) {
-        const int row = pos[0];
-        const _Float16 a = (_Float16)(acc0 + (b0 ? (float)b0[0] : 0.f)), b = (_Float16)(acc1 + (b0 ? (float)b0[half] : 0.f));
+        const _Float16 a = (_Float16)(acc0 + bias0), b = (_Float16)(acc1 + bias1);
         _Float16* dst = kind == 0 ? q_out + h * Dh + j : cache + (size_t)row * (size_t)ld + (kind == 1 ? 0 : Hkv * Dh) + h * Dh + j;
         if (kind == 2) { dst[0] = a; dst[half] = b; return; }
         if (TAB) {
-            const float a32 = acc0 + (b0 ? (float)b0[0] : 0.f), b32 = acc1 + (b0 ? (float)b0[half] : 0.f);
-            const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)row * (size_t)Dh;
-            const float cs = t[j], sn = t[half + j];
+            const float a32 = acc0 + bias0, b32 = acc1 + bias1, cs = tcs, sn = tsn;
             // fp32 fma FIRST, then the rounding to fp16 - as k_rope_f32in and the GEMM epilogue do it: left alone, hipcc fuses the two into
             // v_fma_mixlo_f16 (ONE rounding of the exact product-sum), which differs from fma -> cvt in the last fp16 bit on ties and made the
             // captured decode graph and the eager step disagree by one ulp in a K row every few tokens

@@ -270,6 +270,29 @@ __global__ __launch_bounds__(THREADS) void k_topk_final(const Cand* __restrict__
 
 }  // namespace
 
+namespace {
+// bookkeeping of one batch-1 decode step, ONE launch instead of six elementwise ones inside the captured graph: the picked token becomes the
+// next input id and is appended to the output ring; position, valid key count, ring index and history length advance by one
+__global__ void k_decode_advance(const int64_t* __restrict__ nxt, int64_t* __restrict__ ring, int64_t* __restrict__ cnt, int32_t* __restrict__ tok,
+                                 int32_t* __restrict__ pos, int32_t* __restrict__ len, int32_t* __restrict__ nprev) {
+    if (threadIdx.x == 0) {
+        const int64_t t = nxt[0], c = cnt[0];
+        ring[c] = t;
+        tok[0] = (int32_t)t;
+        cnt[0] = c + 1;
+        pos[0] += 1; len[0] += 1; nprev[0] += 1;
+    }
+}
+}  // namespace
+
+extern "C" int sc_decode_advance(const int64_t* next_token, int64_t* ring, int64_t* ring_index, int32_t* token, int32_t* pos, int32_t* kv_len,
+                                 int32_t* n_prev, sc_stream_t stream) {
+    SC_REQUIRE(next_token && ring && ring_index && token && pos && kv_len && n_prev, "sc_decode_advance: null pointer argument");
+    hipLaunchKernelGGL(k_decode_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, next_token, ring, ring_index, token, pos, kv_len, n_prev);
+    SC_CHECK_LAUNCH("sc_decode_advance");
+    return SC_OK;
+}
+
 extern "C" size_t sc_pick_token_workspace_bytes(int B) { return B > 0 ? (size_t)B * NBLK * sizeof(Part) : 0; }
 
 extern "C" int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out, void* ws,

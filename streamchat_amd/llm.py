@@ -370,9 +370,7 @@ class DecodeGraph:
         else:
             nxt = ops.sample_token(logits, sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=self.hist.view(1, -1), n_prev=self.nprev,
                                    out=self.nxt, ws=self.ws_pick)
-        self.out.index_copy_(0, self.cnt, nxt)
-        self.tok.copy_(nxt)
-        self.pos.add_(1); self.len.add_(1); self.cnt.add_(1); self.nprev.add_(1)
+        ops.decode_advance(nxt, self.out, self.cnt, self.tok, self.pos, self.len, self.nprev)     # ring append + the five counters: one launch
         return logits
 
     def start(self, first_token: int):

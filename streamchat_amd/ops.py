@@ -627,6 +627,15 @@ def decode_qkv_tab(wq, wkv, bq, bkv, x, rms_gamma, rms_eps: float, q_out, cache,
     return q_out
 
 
+def decode_advance(nxt, ring, cnt, tok, pos, kv_len, nprev):
+    """one launch: ring[cnt] = nxt; tok = nxt; cnt, pos, kv_len, nprev += 1 (device scalars of a captured decode step)"""
+    _require_cuda(nxt, ring, cnt, tok, pos, kv_len, nprev)
+    if (nxt.dtype, ring.dtype, cnt.dtype, tok.dtype, pos.dtype, kv_len.dtype, nprev.dtype) != (torch.int64, torch.int64, torch.int64, torch.int32, torch.int32, torch.int32, torch.int32):
+        raise StreamChatHipError("decode_advance: dtypes must be int64 (next, ring, index) / int32 (token, pos, kv_len, n_prev)")
+    with torch.cuda.device(nxt.device):
+        check(_lib.load().sc_decode_advance(ptr(nxt), ptr(ring), ptr(cnt), ptr(tok), ptr(pos), ptr(kv_len), ptr(nprev), stream_ptr(nxt.device)), "sc_decode_advance")
+
+
 def rope_qk_row_(q, q_heads: int, cache, row_index, kv_heads: int, Dh: int, theta: float):
     """decode step: in-place RoPE of the query row `q` [q_heads*Dh] and of the K part of cache row `row_index` (device int32) - one launch."""
     _require_cuda(q, cache, row_index)
