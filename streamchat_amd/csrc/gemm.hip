@@ -598,6 +598,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // in program order, because hipcc's allocator otherwise rotates the 256 accumulation registers through VGPRs every step.
 #define FAT_RD(dst, ad, I) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"((I) * 1024))
 #define FAT_MM(I, J, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(b[J]), "v"(a[I]))
+    // first K half of a tile's FIRST iteration: C = 0 as an inline constant, the accumulator is only written - no 256 v_accvgpr_write per
+    // tile to zero it (they sat in the epilogue's shadow-less tail: ~0.6 us of a ~30 us tile at K = 1024)
+#define FAT_MM0(I, J, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(b[J]), "v"(a[I]))
     // DMA round t (0..7: W, 8..15: A) of iteration k into buffer X.  Iterations past the end of the tile fetch the first
     // iterations of the workgroup's NEXT tile (persistent walk: its data lands while this tile's epilogue stores), or nothing
     // (extent 0 -> zeros) after the last tile: every loop iteration is identical (no tail code: hipcc shuffles all 256
@@ -633,8 +636,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     constexpr int RB = FAT_RB, RC = FAT_RC, DS = FAT_DS, RS = FAT_RS;      // DS: MFMAs per DMA round, RS: MFMAs per fragment read
     constexpr int DMA_BEFORE_RC = (RC - RB + DS - 1) / DS < 16 ? (RC - RB + DS - 1) / DS : 16;
     static_assert(RB + 15 * DS < 128 && RC + 15 * RS < 128 && 15 * RS < RB, "schedule does not fit the iteration");
-    auto iter = [&](auto Xc, int k) {
+    auto iter = [&](auto Xc, auto Fc, int k) {
         constexpr int X = decltype(Xc)::value;
+        constexpr bool FIRST = decltype(Fc)::value;
         const int fin = (k + 1 >= nk) ? 1 : 0;
         const int relax = (PERSIST && k == 0 && tcount > 0) ? 1 : 0;       // stores of the previous tile's epilogue may still be in flight
         // s_nop: the accumulators are zeroed by VALU writes in the loop preheader and the hazard recognizer does not know that the asm
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (t < 64) FAT_MM(i, j, a0, b0);
+            if (t < 64) { if (FIRST) FAT_MM0(i, j, a0, b0); else FAT_MM(i, j, a0, b0); }
             else if (X == 0 || t < 127) FAT_MM(i, j, a1, b1);
             else    // last MFMA of an iteration pair: after the tile's final one, drain the MFMA pipe INSIDE the same asm statement
                     // (the asm MFMAs are invisible to the hazard recognizer, and the compiler is free to put accumulator moves
@@ -677,13 +681,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         const int n0b = __builtin_amdgcn_readfirstlane(tn * BN2 + wc * 128);
         lds_load16(bias ? bias + n0b : W, bias ? 256u : 0u, smem + BIAS_OFF + ((tcount & 1) * 4 + wave) * 1024, (unsigned)lane * 16u, 0u);
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nk; k += 2) {                           // nk is even (dispatch)
-        iter(std::integral_constant<int, 0>{}, k);
-        iter(std::integral_constant<int, 1>{}, k + 1);
+    iter(std::integral_constant<int, 0>{}, std::true_type{}, 0);    // (writes every accumulator: nothing to zero)
+    iter(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+    for (int k = 2; k < nk; k += 2) {                           // nk is even (dispatch)
+        iter(std::integral_constant<int, 0>{}, std::false_type{}, k);
+        iter(std::integral_constant<int, 1>{}, std::false_type{}, k + 1);
     }
     // the asm MFMAs are invisible to the hazard recognizer: drain before reading acc
     // after the last tile: the (zero-fill) DMA rounds of the last two iterations must not land in the LDS of the workgroup that
@@ -873,6 +875,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a0[i]), "v"(b0[i]));
 #undef FAT_RD
 #undef FAT_MM
+#undef FAT_MM0
 }
 
 // ------------------------------------------------------------------------------------------------------------------
