@@ -1,13 +1,13 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r03m; mkdir -p $O
-(timeout 1200 python -m pytest tests/test_gpu_dense.py tests/test_gpu_rope_fused.py tests/test_gpu_vision.py tests/test_gpu_llm.py tests/test_gpu_sharded.py -q -k "not processes and not weak and not rccl and not bare" 2>&1 | tail -6) > $O/pytest.log 2>&1
-for r in 1 2; do for lib in prev new; do
-  if [ $lib = new ]; then unset SC_LIB; else export SC_LIB=$PWD/tools/bin/lib_prev.so; fi
-  echo -n "$lib: "; timeout 300 python tools/bench_gemm.py vit512.fc1+gelu vit512.fc2+res vit512.qkv+b vit512.o+res llm49k.q llm49k.down llm.gateup+swiglu 2>&1 | grep "^{" | python -c "
-import sys, json
-print(' '.join(f\"{json.loads(l)['name']}={json.loads(l)['TFLOPs']}\" for l in sys.stdin))"; done; done > $O/gemm_ab.log 2>&1
-for r in 1 2; do for lib in prev new; do
-  if [ $lib = new ]; then unset SC_LIB; else export SC_LIB=$PWD/tools/bin/lib_prev.so; fi
-  echo -n "$lib: "; timeout 400 python bench.py --no-cpu-baseline --steps 3 --decode-tokens 0 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['encode_ms_per_step'], {k:v['ms_per_step'] for k,v in d['stages'].items() if 'k_' in k})"; done; done > $O/bench_ab.log 2>&1
-unset SC_LIB
-tail -3 $O/pytest.log; cat $O/gemm_ab.log $O/bench_ab.log
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r03n; mkdir -p $O
+(timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/pytest.log 2>&1
+( time timeout 900 python bench.py 2> $O/bench.err | tail -1 > $O/bench.json ) 2> $O/bench.time
+bash tools/run_profile.sh r03 > $O/profile.log 2>&1
+tail -4 $O/pytest.log; cat $O/bench.time; tail -3 $O/bench.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r03n/bench.json'))
+print(d['value'], d['ms_per_step'], d['encode_frames_per_s'], d.get('decode_tokens_per_s'))
+print(d['roofline'])
+print({k:(v['achieved'],v['frac']) for k,v in d['roofline_stages'].items()})
+print(json.dumps(d['cpu_baseline'])[:900])
+print(d['power'])
+PY
