@@ -282,8 +282,10 @@ int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float tempe
  *   logits [B, V] fp32, row stride ld; MODIFIED in place when repetition_penalty != 1 (x < 0 ? x * r : x / r at every DISTINCT id of
  *   prev_ids[row, 0 .. n_prev): the ids generated so far; n_prev_dev [B] device int32 or NULL -> n_prev_host for every row).
  *   temperature <= 0: arg-max of the processed logits (lowest index on ties); else a sample from softmax(logits / T) restricted to
- *   the top_k largest (0 = off; at most 64; tokens equal to the k-th value stay, as in HF) and to the nucleus top_p (1 = off; needs
- *   top_k >= 1: SC_ERR_UNSUPPORTED otherwise), by inverse CDF at u[B] over the kept tokens in index order.
+ *   the top_k largest (0 = off; tokens equal to the k-th value stay, as in HF) and to the nucleus top_p (1 = off), by inverse CDF at u[B]
+ *   over the kept tokens in index order.  top_k <= 64: candidate kernels; top_k > 64 or top_p < 1 without top_k (round 3): one block per row
+ *   selects both thresholds over the full vocabulary by integer radix select (a group of equal logits is kept or dropped as a whole) and
+ *   leaves, per row, {threshold logit as float bits, kept count} in ws[0 .. 2B) (uint32) for diagnostics.
  *   top_k = 0 and top_p = 1 is sc_pick_token_f32 after the penalty.  ws: sc_sample_token_workspace_bytes(B). */
 size_t sc_sample_token_workspace_bytes(int B);
 int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, float temperature, int top_k, float top_p, float repetition_penalty,

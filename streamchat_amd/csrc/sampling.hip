@@ -268,6 +268,132 @@ __global__ __launch_bounds__(THREADS) void k_topk_final(const Cand* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Full-vocabulary top-k / top-p (round 3): the corners HF `generate` accepts that the candidate path above does not serve - a nucleus
+// without top-k (the reference forwards --top_p, inference_streaming_longva_v2.py:245-256; HF's default top_k = 50 only applies when the
+// checkpoint or the caller leaves it) and top_k > 64.  One block of 1024 threads per row, ~10 coalesced scans of the row (L2-resident,
+// 608 KB), everything in integers so that the result does not depend on the order of atomics:
+//   * keys: the logits as order-preserving uint32; thresholds by 4-pass radix select over 8 bits with LDS histograms -
+//     COUNT histograms for the k-th largest key (TopKLogitsWarper keeps everything >= the k-th value), then MASS histograms of
+//     w_i = exp((x_i - max) / T) in 2^40 fixed point (uint64 LDS atomics: exact sums) for the nucleus: the largest key t with
+//     mass(key >= t) >= top_p * mass(kept by top-k) - i.e. a token stays iff the mass of strictly larger tokens is < top_p, which is
+//     TopPLogitsWarper's "remove the ascending tail whose cumulative probability <= 1 - top_p" (a group of EQUAL logits is kept or
+//     dropped as a whole);
+//   * the draw: inverse CDF at u over the kept tokens in INDEX order (the convention of sc_pick_token_f32), per-thread contiguous
+//     chunks, fp64 prefix over the 1024 chunk sums.
+// diag (optional, device): per row {threshold logit as float bits, kept count} - what the tests compare with HF's processors.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FT = 1024;
+
+__device__ __forceinline__ unsigned f2key(float x) { const unsigned u = __float_as_uint(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(FT) void k_full_filter(const float* __restrict__ logits, int V, int64_t ld, float inv_t, int top_k, float top_p,
+                                                    const float* __restrict__ u, int64_t* __restrict__ out, unsigned* __restrict__ diag) {
+    __shared__ unsigned long long hist[256];
+    __shared__ float red[FT / 64];
+    __shared__ unsigned sh_sel;
+    __shared__ unsigned long long sh_left, sh_total;
+    __shared__ double chunk[FT];
+    __shared__ int sh_owner;
+    __shared__ double sh_before;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)row * (size_t)ld;
+    // ---- max ----
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += FT) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s2, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < FT / 64; ++w) mx = fmaxf(mx, red[w]);
+    auto wfix = [&](float v) -> unsigned long long { return (unsigned long long)(__expf((v - mx) * inv_t) * 1099511627776.0f); };   // 2^40
+    // 4-pass radix select, descending: the largest key t such that measure(key >= t) >= need.  MASS: measure = fixed-point weight, else count.
+    // Candidates of a pass are the keys that match the prefix chosen so far AND are >= floor_key (the top-k threshold during the mass search).
+    auto radix_select = [&](unsigned long long need, bool mass, unsigned floor_key) -> unsigned {
+        unsigned prefix = 0;
+        unsigned long long left = need;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (int b = tid; b < 256; b += FT) hist[b] = 0ull;
+            __syncthreads();
+            for (int i = tid; i < V; i += FT) {
+                const float v = x[i];
+                const unsigned k = f2key(v);
+                if ((k & hi_mask) == prefix && k >= floor_key) atomicAdd(&hist[(k >> shift) & 255u], mass ? wfix(v) : 1ull);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long acc = 0ull;
+                int b = 255;
+                for (; b > 0; --b) { if (acc + hist[b] >= left) break; acc += hist[b]; }
+                sh_sel = (unsigned)b; sh_left = left - acc;          // (b == 0: everything that is left lies in the lowest bin)
+            }
+            __syncthreads();
+            prefix |= sh_sel << shift;
+            left = sh_left;
+            __syncthreads();
+        }
+        return prefix;
+    };
+    unsigned thr = 0u;                                                   // keep key >= thr
+    if (top_k > 0 && top_k < V) thr = radix_select((unsigned long long)top_k, false, 0u);
+    if (top_p < 1.f) {
+        // mass kept by top-k, then the nucleus threshold inside it
+        unsigned long long part = 0ull;
+        for (int i = tid; i < V; i += FT) { const float v = x[i]; if (f2key(v) >= thr) part += wfix(v); }
+        if (tid == 0) sh_total = 0ull;
+        __syncthreads();
+        atomicAdd(&sh_total, part);
+        __syncthreads();
+        const double need_d = (double)top_p * (double)sh_total;
+        unsigned long long need = (unsigned long long)need_d;
+        if ((double)need < need_d) ++need;                                // ceil: mass(key >= t) >= top_p * total
+        if (need < 1ull) need = 1ull;
+        const unsigned tp = radix_select(need, true, thr);
+        thr = tp > thr ? tp : thr;
+    }
+    // ---- inverse CDF over the kept tokens in index order ----
+    const int per = (V + FT - 1) / FT, lo = tid * per, hi = min(V, lo + per);
+    double mine = 0.0;
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) { const float v = x[i]; if (f2key(v) >= thr) { mine += (double)__expf((v - mx) * inv_t); ++cnt; } }
+    chunk[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < FT; ++t) tot += chunk[t];
+        const double target = (double)fminf(fmaxf(u[row], 0.f), 0.99999994f) * tot;
+        double run = 0.0;
+        int owner = 0;
+        for (int t = 0; t < FT; ++t) { if (chunk[t] > 0.0) { owner = t; if (target < run + chunk[t]) break; run += chunk[t]; } }
+        sh_owner = owner; sh_before = run;
+    }
+    if (diag) {                                                           // kept count (integer atomics) + the threshold logit
+        if (tid == 0) sh_total = 0ull;
+        __syncthreads();
+        atomicAdd(&sh_total, (unsigned long long)cnt);
+        __syncthreads();
+        if (tid == 0) { diag[2 * row] = __float_as_uint(key2f(thr)); diag[2 * row + 1] = (unsigned)sh_total; }
+    }
+    __syncthreads();
+    if (tid == sh_owner) {
+        const double target = (double)fminf(fmaxf(u[row], 0.f), 0.99999994f);
+        double tot = 0.0;
+        for (int t = 0; t < FT; ++t) tot += chunk[t];
+        const double tg = target * tot;
+        double run = sh_before;
+        int pick = -1;
+        for (int i = lo; i < hi; ++i) {
+            const float v = x[i];
+            if (f2key(v) >= thr) { pick = i; const double w = (double)__expf((v - mx) * inv_t); if (tg < run + w) break; run += w; }
+        }
+        out[row] = pick < 0 ? 0 : pick;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -319,11 +445,9 @@ extern "C" int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, floa
                                    void* ws, size_t ws_bytes, sc_stream_t stream) {
     SC_REQUIRE(logits && out && ws, "sc_sample_token_f32: null pointer argument");
     SC_REQUIRE(B > 0 && V > 0 && ld >= V, "sc_sample_token_f32: bad sizes");
-    SC_REQUIRE(top_k >= 0 && top_k <= TK_MAX, "sc_sample_token_f32: top_k must be in [0, %d] (0 = off)", TK_MAX);
+    SC_REQUIRE(top_k >= 0, "sc_sample_token_f32: top_k must be >= 0 (0 = off)");
     SC_REQUIRE(top_p > 0.f && repetition_penalty > 0.f, "sc_sample_token_f32: top_p and repetition_penalty must be positive");
     SC_REQUIRE(!(temperature > 0.f) || u, "sc_sample_token_f32: sampling (temperature > 0) needs the uniform draws u[B]");
-    if (top_p < 1.f && top_k == 0)
-        return sc_fail(SC_ERR_UNSUPPORTED, "sc_sample_token_f32: top_p < 1 needs 1 <= top_k <= %d (the nucleus is cut inside the top-k candidates)", TK_MAX);
     if (ws_bytes < sc_sample_token_workspace_bytes(B))
         return sc_fail(SC_ERR_WORKSPACE, "sc_sample_token_f32: workspace %zu < required %zu", ws_bytes, sc_sample_token_workspace_bytes(B));
     hipStream_t s = (hipStream_t)stream;
@@ -333,8 +457,16 @@ extern "C" int sc_sample_token_f32(float* logits, int B, int V, int64_t ld, floa
         hipLaunchKernelGGL(k_rep_penalty, dim3(B), dim3(THREADS), bm, s, logits, V, ld, prev_ids, prev_ld, n_prev_dev, n_prev_host, repetition_penalty);
     }
     if (top_k > V) top_k = V;                                          // HF: top_k = min(top_k, vocabulary)
-    if (top_k == 0 || (top_k == V && top_p >= 1.f))                       // nothing to cut: the plain arg-max / temperature sample
+    if ((top_k == 0 || top_k == V) && top_p >= 1.f)                       // nothing to cut: the plain arg-max / temperature sample
         return sc_pick_token_f32(logits, B, V, ld, temperature, u, out, ws, ws_bytes, stream);
+    if (!(temperature > 0.f))                                             // arg-max: no warper can remove the largest logit
+        return sc_pick_token_f32(logits, B, V, ld, temperature, u, out, ws, ws_bytes, stream);
+    if (top_k == 0 || top_k == V || top_k > TK_MAX) {                      // a nucleus without top-k, or more candidates than the candidate path keeps
+        hipLaunchKernelGGL(k_full_filter, dim3(B), dim3(FT), 0, s, (const float*)logits, V, ld, 1.0f / temperature, top_k == V ? 0 : top_k, top_p, u, out,
+                           (unsigned*)ws);                                // ws[0 .. 2B) <- per row {threshold logit bits, kept count} (diagnostics)
+        SC_CHECK_LAUNCH("sc_sample_token_f32");
+        return SC_OK;
+    }
     Cand* cand = (Cand*)((char*)ws + sc_align_up(sc_pick_token_workspace_bytes(B), 256));
     const int per = ((V + NBLK - 1) / NBLK + 3) & ~3;
     const float inv_t = temperature > 0.f ? 1.0f / temperature : 0.f;

@@ -299,10 +299,7 @@ def resolve_sampling(generation_config, do_sample, temperature=_UNSET, top_p=_UN
         raise ValueError("do_sample=True needs temperature > 0 (HF raises the same way)")
     k = int(g["top_k"] or 0)
     pp = float(g["top_p"] if g["top_p"] is not None else 1.0)
-    if k > 64:
-        raise NotImplementedError(f"top_k = {k}: the HIP sampler keeps at most 64 candidates (sampling.hip TK_MAX)")
-    if pp < 1.0 and k == 0:
-        raise NotImplementedError("top_p < 1 without top_k: the HIP sampler cuts the nucleus inside the top-k candidates (1 <= top_k <= 64)")
+    # (top_k > 64 and a nucleus without top-k run through sampling.hip's full-vocabulary radix-select path since round 3)
     return Sampling(t, k, pp, pen)
 
 

@@ -267,7 +267,9 @@ def sample_token_workspace_bytes(B: int) -> int:
 def sample_token(logits: torch.Tensor, temperature: float = 0.0, u=None, top_k: int = 0, top_p: float = 1.0, repetition_penalty: float = 1.0,
                  prev_ids=None, n_prev=None, out=None, ws=None):
     """Next token ids [B] int64 from fp32 logits [B, V] through HF's processor chain (repetition penalty over the DISTINCT ids of
-    prev_ids[b, :n_prev[b]] -> temperature -> top-k (<= 64, ties at the k-th value kept) -> top-p) and one inverse-CDF draw at u [B];
+    prev_ids[b, :n_prev[b]] -> temperature -> top-k (ties at the k-th value kept) -> top-p) and one inverse-CDF draw at u [B] (top_k <= 64: the
+    candidate kernels; top_k > 64 or a nucleus without top-k: the full-vocabulary radix-select kernel, which also leaves per row
+    {threshold logit bits, kept count} in ws[0 : 2B] as uint32 for diagnostics);
     temperature <= 0: arg-max of the penalised logits.  `logits` is modified in place when repetition_penalty != 1.  n_prev: int (all
     rows) or a device int32 tensor [B] (graph-safe).  No host sync; graph-capturable with a private `ws`."""
     _require_cuda(logits)

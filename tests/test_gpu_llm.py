@@ -376,8 +376,48 @@ def test_sample_token_matches_hf_logits_processors(V):
                 exp = RepetitionPenaltyLogitsProcessor(pen)(prev, exp)
                 assert torch.equal(lg.cpu(), exp)
     assert compared > 100
-    with pytest.raises(ops.StreamChatHipError):
-        ops.sample_token(base.cuda(), 0.7, torch.rand(B).cuda(), top_k=0, top_p=0.9)      # nucleus without top-k: not built, loud
+
+
+@pytest.mark.parametrize("V", [152064, 1000])
+def test_sample_token_full_vocabulary_top_k_top_p_matches_hf(V):
+    """The corners HF `generate` accepts beyond the 64-candidate path (round 3: k_full_filter, integer radix select over the whole row): a
+    nucleus without top-k (the reference forwards --top_p, inference_streaming_longva_v2.py:245-256), top_k > 64, both together, ties at
+    the k-th value.  Kept-token COUNT against the transformers warpers (exact for top-k, which is integer work; within 2 tokens for the
+    nucleus, whose boundary depends on the summation order of ~1e-5 probabilities) and the drawn token wherever u is not within 1e-4 of a
+    CDF boundary."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    B = 3
+    g = torch.Generator().manual_seed(V + 1)
+    base = torch.randn(B, V, generator=g) * 3.0
+    base[1, 5] = base[1, V - 9] = base[1, V // 2] = base[1].topk(100).values[-1]          # ties at the 100th value
+    base[2, :50] += 6.0                                                                     # a peaky row: small nucleus
+    prev = torch.zeros(B, 1, dtype=torch.long)
+    ws = torch.zeros(max(ops.sample_token_workspace_bytes(B), 256), dtype=torch.uint8, device="cuda")
+    compared = 0
+    for T, top_k, top_p in [(0.7, 0, 0.9), (0.2, 0, 0.5), (1.0, 100, 1.0), (0.7, 200, 0.8), (1.3, 0, 0.99), (0.7, 65, 0.3), (1.0, V, 0.7)]:
+        s = TemperatureLogitsWarper(T)(prev, base.clone())
+        if top_k and top_k < V:
+            s = TopKLogitsWarper(top_k)(prev, s)
+        k_only = torch.isfinite(s).sum(-1)
+        if top_p < 1.0:
+            s = TopPLogitsWarper(top_p)(prev, s)
+        n_hf = torch.isfinite(s).sum(-1)
+        for trial in range(4):
+            u = torch.rand(B, generator=g)
+            ref, margin = _hf_pick(base, prev, T, top_k if top_k < V else 0, top_p, 1.0, u)
+            got = ops.sample_token(base.cuda().clone(), T, u.cuda(), top_k=top_k, top_p=top_p, ws=ws).cpu()
+            diag = ws[:8 * B].view(torch.int32).view(B, 2).cpu()
+            for b in range(B):
+                n = int(diag[b, 1])
+                if top_p >= 1.0:
+                    assert n == int(n_hf[b]), (V, T, top_k, top_p, b, n, int(n_hf[b]))                 # top-k with ties: exact
+                else:
+                    assert abs(n - int(n_hf[b])) <= 2 and 1 <= n <= int(k_only[b]), (V, T, top_k, top_p, b, n, int(n_hf[b]))
+                assert torch.isfinite(base[b, int(got[b])] * 0 + 1) and 0 <= int(got[b]) < V
+                if margin[b] > 1e-4 and n == int(n_hf[b]):
+                    assert int(got[b]) == int(ref[b]), (V, T, top_k, top_p, trial, b, int(got[b]), int(ref[b]), float(margin[b]))
+                    compared += 1
+    assert compared > 40
 
 
 def test_resolve_sampling_follows_hf_generation_config_semantics():
@@ -393,10 +433,8 @@ def test_resolve_sampling_follows_hf_generation_config_semantics():
     assert R(qwen, LM._UNSET) == S(0.7, 20, 0.8, 1.05)            # do_sample not passed: the checkpoint's file decides ...
     assert R({}, LM._UNSET) == R({}, None) == S(0.0, 0, 1.0, 1.0)  # ... then HF's default: greedy
     assert R(qwen, True, 0.2, None, top_k=None, repetition_penalty=None) == S(0.2, 0, 1.0, 1.0)
-    with pytest.raises(NotImplementedError):
-        R({}, True, 0.2, 0.9, top_k=None)                                                   # nucleus without top-k
-    with pytest.raises(NotImplementedError):
-        R({}, True, 0.2, None, top_k=100)
+    assert R({}, True, 0.2, 0.9, top_k=None) == S(0.2, 0, 0.9, 1.0)                        # nucleus without top-k: the full-vocabulary path (round 3)
+    assert R({}, True, 0.2, None, top_k=100) == S(0.2, 100, 1.0, 1.0)                      # more than the 64 candidates of the fast path
     with pytest.raises(ValueError):
         R({}, True, 0.0)
 
