@@ -124,9 +124,11 @@ def _rms(x, w, eps):
     return w * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
 
 
-def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6):
+def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6, last_only=False, head_chunk=None):
     """logits [L, vocab] for inputs_embeds [L, H] (causal, positions 0..L-1): RMSNorm -> q/k/v (bias) -> rotate-half RoPE ->
-    GQA causal attention -> o_proj -> +res -> RMSNorm -> down(silu(gate) * up) -> +res; final norm; lm_head."""
+    GQA causal attention -> o_proj -> +res -> RMSNorm -> down(silu(gate) * up) -> +res; final norm; lm_head.
+    last_only: logits of the last position only ([vocab]); head_chunk: attention computed for that many heads at a time (same
+    arithmetic per head; bounds the [heads, L, L] score tensor for contexts of ~10 k tokens in the composed tests)."""
     L, H = embeds.shape
     x = embeds
     pos = torch.arange(L, device=x.device, dtype=torch.float32)
@@ -147,13 +149,18 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
         q, k = rot(q), rot(k)
         k = k.repeat_interleave(heads // kv_heads, dim=0)
         v = v.repeat_interleave(heads // kv_heads, dim=0)
-        a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v
+        if head_chunk:
+            a = torch.cat([torch.softmax(q[j:j + head_chunk] @ k[j:j + head_chunk].transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v[j:j + head_chunk]
+                           for j in range(0, heads, head_chunk)])
+        else:
+            a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v
         x = x + F.linear(a.transpose(0, 1).reshape(L, heads * head_dim), sd[p + "self_attn.o_proj.weight"])
         h = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
         m = F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"])
         x = x + F.linear(m, sd[p + "mlp.down_proj.weight"])
-    x = _rms(x, sd["model.norm.weight"], eps)
-    return F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"])
+    x = _rms(x[-1:] if last_only else x, sd["model.norm.weight"], eps)
+    out = F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"])
+    return out[0] if last_only else out
 
 
 # ---------------------------------------------------------------------------------------------------------

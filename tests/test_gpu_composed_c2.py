@@ -171,7 +171,7 @@ def c2():
         cpu = _run_policy(ref, RefBert(), tok, rec_cpu)
     finally:
         U.weighted_kmeans_feature, ops.sim_topk = saved
-    return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps)
+    return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps, dev=dev)
 
 
 def test_c2_short_memory_frames_identical(c2):
@@ -209,3 +209,49 @@ def test_c2_merged_centroids_close(c2):
     for k in range(5):
         rows = np.nonzero(labels == k)[0]
         assert_close_fp16(hip_feats[rows].mean(0), ref[rows].mean(0), max_rel=6e-3, what=f"centroid {k} ({len(rows)} frames)")
+
+
+def test_c3_prefill_logits_and_first_token_on_the_retrieved_context(c2):
+    """The LAST stage of the chain (BASELINE.json configs[2]) on what the stages above produced: the [short | retrieved] frame tokens of
+    the SAME stream (5 + 8 + 8 frames = 12 096 visual tokens) spliced into the reference's answer prompt and prefilled through a Qwen2
+    stack at the 7B widths (2 layers, random-init: 28 / 4 heads x 128, rotary epilogue GEMMs, pre-scaled causal GQA attention, SwiGLU) -
+    HIP on the fp16 HIP features vs oracle/torch_ref fp32 on the CPU path's fp32 features: last-position logits within the fp16
+    tolerance and the same first token (margin between the two best logits printed)."""
+    from oracle import torch_ref as R
+    from streamchat_amd import llm as LM, streaming as S, synthetic
+    from streamchat_amd.conversation import conv_templates
+    from streamchat_amd.mm_utils import tokenizer_image_token
+    from tests._tol import assert_close_fp16
+    dev = c2["dev"]
+    assert c2["hip"]["retrieved"] == c2["cpu"]["retrieved"] and c2["hip"]["short"] == c2["cpu"]["short"]
+    frames = c2["hip"]["short"] + [f for r in c2["hip"]["retrieved"] for f in r]
+    cfg = LM.Qwen2ConfigLite(**dict(LM.QWEN2_7B, layers=2, vocab=8192))
+    sd = LM.random_qwen2_state_dict(cfg, seed=4, device=dev)
+    qs = S.build_answer_prompt(QUESTION, c2["hip"]["texts"][-1], None)
+    conv = conv_templates["qwen_1_5"].copy()
+    conv.append_message(conv.roles[0], qs)
+    conv.append_message(conv.roles[1], None)
+    ids = tokenizer_image_token(conv.get_prompt(), synthetic.SyntheticTokenizer(), -200, return_tensors="pt")
+    ids = torch.where(ids >= 0, ids % cfg.vocab, ids)                       # synthetic ids into the small test vocabulary (the sentinel stays -200)
+    assert int((ids == -200).sum()) == 1
+    # ---- HIP: pieces spliced without a cat, prefill ----
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, device=dev, max_seq=len(frames) * 576 + ids.numel() + 8))
+    pieces = [c2["feats"][f].reshape(-1, 3584) for f in frames]
+    _, _, _, _, embeds, _ = model.prepare_inputs_embeddings_for_multimodal(ids.unsqueeze(0), None, None, None, None, [pieces], ["video"])
+    assert embeds.shape[1] == len(frames) * 576 + ids.numel() - 1
+    model.lm.reset_cache()
+    logits = model.lm.forward(embeds[0]).float().cpu()
+    # ---- CPU fp32: the same prompt rows around the fp32 features of the same frames ----
+    table = sd["model.embed_tokens.weight"].float().cpu()
+    p = int((ids == -200).nonzero()[0])
+    img = torch.cat([c2["ref"][f].reshape(-1, 3584) for f in frames])
+    emb32 = torch.cat([table[ids[:p]], img, table[ids[p + 1:]]])
+    sd32 = {k: v.float().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = R.qwen2_logits(sd32, emb32, heads=cfg.heads, kv_heads=cfg.kv_heads, layers=2, head_dim=cfg.head_dim, theta=cfg.rope_theta, eps=cfg.eps,
+                             last_only=True, head_chunk=4)
+    top = ref.topk(2).values
+    print(f"\n[C3] prefill of {emb32.shape[0]} tokens (2 Qwen2-7B-width layers): first token HIP {int(logits.argmax())} / CPU {int(ref.argmax())}; "
+          f"best-minus-second logit {float(top[0] - top[1]):.3e} of max |logit| {float(ref.abs().max()):.3f}")
+    assert_close_fp16(logits, ref, max_rel=6e-3, what="C3 last-position logits (12 k-token context)")
+    assert int(logits.argmax()) == int(ref.argmax())
