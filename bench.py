@@ -23,8 +23,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the pool's host driver only supports dmabuf IPC: RCCL across processes needs it (task brief)
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

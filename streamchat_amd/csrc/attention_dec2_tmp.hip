@@ -1,0 +1,747 @@
+// Fused multi-head attention for gfx950 (CDNA4), fp16 in/out, fp32 online softmax.
+//   ViT-L: S = 577, 16 heads x 64, non-causal  (HF CLIPAttention behind reference clip_encoder.py:76)
+//   BERT : padding-masked (kv_len), 12..16 heads x 32/64 (reference utiles.py:707,728)
+//   Qwen2: causal GQA 28/4 heads x 128 over 26k-49k stacked frame tokens (reference llava_qwen.py:155)
+//
+// Orientation: everything is computed TRANSPOSED so that one lane owns one query column end to end.
+//   S^T[kv][q] = K[kv][:] . Q[q][:]      A = K fragment (LDS, ds_read_b128),  B = Q fragment (registers)
+//   O^T[d][q] += V^T[d][kv] . P^T[kv][q]  A = V^T fragment (row-major V tile in LDS read with
+//                                          ds_read_b64_tr_b16, the gfx950 transpose read), B = P^T (registers)
+// With v_mfma_f32_16x16x32_f16 the C/D layout is col = lane&15, row = (lane>>4)*4 + r, so the P values a lane
+// produced for its query column are exactly the B-operand k-slots it must feed to the second MFMA (the
+// k-slot <-> kv-row bijection is applied to the V rows the transpose read fetches).  Row max / row sum /
+// rescale factors are therefore per-lane scalars: no LDS round trip and no cross-lane traffic for P; the row max across the
+// 4 lane groups is two VALU row swaps (v_permlane16_swap / v_permlane32_swap).
+//
+// Block = 4 waves x QB q-blocks of 16 queries (QB = 2; 3 for long Dh = 128 prefill); KV tiles of 64 rows double-buffered in
+// LDS by 16-byte buffer_load ... lds (the resource extent is the valid cache length: rows past kv_len arrive as zeros);
+// bank-conflict-free XOR swizzles on the per-lane source address and on the reads.  The KV loop is a general tile body plus a
+// steady-state loop with no mask, no row max and no O rescale (see the notes at the loop); what bounds it - LDS fragment
+// traffic and the SIMD issue port - is measured in tools/probes/ and summarised in DESIGN.md section 4.
+#include "sc_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef short sc_s4 __attribute__((ext_vector_type(4)));
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
+
+constexpr int KVT = 64;   // kv rows per tile
+
+// 16-byte LDS-DMA through a raw buffer resource (base, extent in bytes): lane address = base + voff + soff, destination = the
+// wave-uniform LDS pointer + lane * 16; out-of-range lanes write zeros.  A free function because an opaque
+// __amdgpu_buffer_rsrc_t inside a lambda of the kernel silently drops the kernel's host stub.
+__device__ __forceinline__ void lds_load16(const void* base, int extent, char* lds, unsigned voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// PRE (SC_ATTN_Q_PRESCALED): the caller's Q already carries the softmax scale in the log2 domain (q * scale * log2 e, applied by the
+// PRODUCER of q to its fp32 accumulators before the one rounding to fp16: the rotary / column-scale epilogues of gemm.hip, k_decode_qkv,
+// k_rope_f32in).  In the steady-state loop the softmax reference then enters through the C operand of the first S MFMA of a k-step
+// chain (accumulators start at -m instead of 0): the scores leave the matrix pipe as s - m and p = 2^that needs no FMA - one VALU
+// instruction less per score in an issue-bound loop (+4 % at 49 k tokens, +3 % on the ViT shape, profiles/r03_run2_attn_prescale_ab.md).
+// Scaling an fp16 q inside this kernel instead (a second rounding) was measured and rejected: error x2-7 on peaky rows.
+template <int DH, int QB, bool CAUSAL, int CH, bool PRE>
+__global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+                                              const _Float16* __restrict__ Vp, int ldv, _Float16* __restrict__ O, int ldo, int Sq,
+                                              int Skv, int Hq, int Hkv, float scale_log2, const int* __restrict__ kv_len,
+                                              float* __restrict__ part, int nsplit, int B, int q_hs, int o_hs, long q_bs, long o_bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = KVT * DH * 2;            // bytes per K (or V) tile
+    constexpr int STAGE = 2 * TILE;
+    constexpr int GPT = TILE / 16 / 256;          // 16-byte granules per thread per operand tile (2 or 4)
+    constexpr int DS = DH / 32;                   // MFMA k-steps over the head dim
+    constexpr int DB = DH / 16;                   // 16-row blocks of O^T
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    // 1-D grid, XCD-aware (block i runs on XCD i % 8): each XCD walks its own queue of (batch, kv-head, q-block) "pairs"; the
+    // G = Hq/Hkv query heads of a pair are CONSECUTIVE entries of the same XCD's queue, so they run together on that XCD and
+    // stream the same K/V tiles through its L2 once (PMC before: 69.5 GB fetched per 49k-token GQA launch, heads of a group
+    // scattered over 7 XCDs).  q-blocks are taken in DESCENDING order: under a causal mask the longest blocks go first.
+    const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16);
+    const int G = Hq / Hkv;
+    const int split = blockIdx.x % nsplit, bid = blockIdx.x / nsplit;            // split-KV (flash-decoding) index fastest
+    const int xcd = bid & 7, j = bid >> 3;
+    const int pair = (j / G) * 8 + xcd;
+    const int npairs = nqb * Hkv * B;
+    if (pair >= npairs) return;                                                  // padding of the per-XCD queues (whole block exits)
+    const int hk = pair % Hkv, h = hk * G + j % G;
+    const int qi = (pair / Hkv) % nqb, b = pair / (Hkv * nqb);
+    const int qblk0 = (nqb - 1 - qi) * (4 * QB * 16);
+    const int qw0 = qblk0 + wave * (QB * 16);
+    const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
+    const int coff = Skv - Sq;                    // causal: query i sits at kv position i + coff
+    const bool wave_live = qw0 < Sq;              // false: every query row of this wave is padding of the last q-block
+    const int qw_last = min(qw0 + QB * 16, Sq) - 1;
+
+    int nt = (kv_valid + KVT - 1) / KVT;
+    if (CAUSAL) {
+        const int last_q = min(qblk0 + 4 * QB * 16, Sq) - 1;
+        const int lim = (last_q + coff) / KVT + 1;
+        nt = nt < lim ? nt : lim;
+    }
+
+    // ---- Q fragments (registers, loaded once) ----
+    sc_h8 qf[QB][DS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qr = qw0 + qb * 16 + rl;
+        qr = qr < Sq ? qr : Sq - 1;
+        const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            qf[qb][ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+        }
+    }
+
+    // ---- staging sources ----
+    const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
+    const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
+    // granule q (16 bytes) of a staged tile -> source row and swizzled 16-byte column slot, for K and for V
+    auto gran = [&](int q, int& kr, int& ks, int& vr, int& vs) {
+        if (DH == 32) {                         // 64-byte rows: 4 granules
+            kr = q >> 2;
+            ks = (q & 3) ^ ((0x78 >> (2 * ((kr >> 2) & 3))) & 3);      // f = {0,2,3,1}[(row>>2)&3]
+            vr = q >> 2;
+            vs = (q & 3) ^ (((vr >> 2) & 1) << 1);
+        } else if (DH == 64) {
+            kr = 2 * (q >> 4) + ((q & 15) >> 3);
+            ks = (q & 7) ^ ((q >> 4) & 7);
+            vr = q >> 3;
+            vs = (q & 7) ^ (((vr >> 1) & 3) << 1);
+        } else {
+            kr = q >> 4;
+            ks = (q & 15) ^ (kr & 15);
+            vr = q >> 4;
+            vs = (q & 15) ^ ((vr & 7) << 1);
+        }
+    };
+    // K/V tiles are fetched with buffer_load ... lds: uniform tile offset in an SGPR (soffset) + a constant per-lane 32-bit
+    // offset (voffset), so the steady state has no per-tile VALU address arithmetic at all, and the hardware bounds check of
+    // the buffer resource returns zeros for rows >= Skv of the ragged last tile (K = 0 scores are masked below; V = 0 is finite).
+    unsigned k_lo[GPT], v_lo[GPT];
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        int kr, ks, vr, vs;
+        gran(j * 256 + tid, kr, ks, vr, vs);
+        k_lo[j] = ((unsigned)kr * (unsigned)ldk + (unsigned)ks * 8u) * 2u;
+        v_lo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)vs * 8u) * 2u;
+    }
+    // extent = the VALID rows only: rows in [kv_valid, Skv) of a cache hold whatever the allocator left there, and a NaN in V
+    // would survive the multiplication by p = 0 in the P.V MFMA; beyond the extent the DMA writes zeros instead
+    const int k_bytes = kv_valid > 0 ? (int)(((unsigned)(kv_valid - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_bytes = kv_valid > 0 ? (int)(((unsigned)(kv_valid - 1) * (unsigned)ldv + DH) * 2u) : 0;
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * STAGE;
+        const int k_so = t * KVT * ldk * 2, v_so = t * KVT * ldv * 2;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            lds_load16(kbase, k_bytes, base + (j * 256 + wave * 64) * 16, k_lo[j], k_so);
+            lds_load16(vbase, v_bytes, base + TILE + (j * 256 + wave * 64) * 16, v_lo[j], v_so);
+        }
+    };
+
+    // ---- read addresses ----
+    int k_off[DS];   // K fragment byte offset of (row rl, d-step ds) inside a 16-row block
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+        if (DH == 32) k_off[ds] = rl * 64 + ((g ^ ((0x78 >> (2 * ((rl >> 2) & 3))) & 3)) << 4);
+        else if (DH == 64) k_off[ds] = (rl >> 1) * 256 + ((((rl & 1) << 3) | ((ds * 4 + g) ^ ((rl >> 1) & 7))) << 4);
+        else k_off[ds] = rl * 256 + (((ds * 4 + g) ^ rl) << 4);
+    }
+    constexpr int KBLK = 16 * DH * 2;             // bytes per 16 kv rows
+    // V transpose-read: this lane supplies row (4g + (rl>>2)) [+16 for the second read] of a 32-row chunk,
+    // 8-byte column chunk (rl&3) of the 16-column d-block db
+    const int vrow = 4 * g + (rl >> 2);
+    int v_off[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        if (DH == 32) v_off[db] = vrow * 64 + ((db ^ (g & 1)) << 5) + (rl & 3) * 8;
+        else if (DH == 64) v_off[db] = vrow * 128 + ((db ^ ((vrow >> 1) & 3)) << 5) + (rl & 3) * 8;
+        else v_off[db] = vrow * 256 + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+    }
+    constexpr int VROW = DH * 2;
+
+    sc_f4 o[DB][QB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int j = 0; j < QB; ++j) o[i][j] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+    // Row sums on the matrix pipe at head dim <= 64: one extra MFMA per (q-block, 32 kv rows) with an all-ones A operand gives
+    // sum_kv P[kv][q] in every row of a 16 x 16 accumulator (the fp16-rounded P, exactly what P.V uses; complete over the four lane
+    // groups, so no shuffles at the end).  At Dh = 64 the loop is bound by the VALU port (2.8 VALU per MFMA, the pipe 25-40 % busy):
+    // this trades 8 v_add per lane and chunk for half an MFMA.  At Dh = 128 the pipe (and the board's power) was the limit and the VALU adds
+    // stayed - until the pre-scaled-q mode took the FMA out of the loop: with it the adds are the next VALU instructions to go and the ones-MFMA
+    // wins there too (+1 % at 49 k: 1262 -> 1274 TF, profiles/r03_run9), so PRE takes the matrix-pipe row sums at every head dim.
+    constexpr bool LSUM_MFMA = (DH <= 64) || PRE;
+    sc_f4 ol[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) ol[qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    const sc_h8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+
+    // split-KV: this block covers tiles [t_lo, t_hi)
+    const int per = (nt + nsplit - 1) / nsplit;
+    const int t_lo = split * per;
+    const int t_hi = (t_lo + per) < nt ? (t_lo + per) : nt;
+    if (t_lo < t_hi) stage(0, t_lo);
+    __syncthreads();
+    // m_run is the REFERENCE max of a row in the scaled log2 domain: p = 2^(s - m_run); O and l are relative to the same reference,
+    // so the final O / l does not depend on it.  Two tile bodies share the loop:
+    //   GENERAL: masks, moves the reference to the true running max and rescales O (exact online softmax step);
+    //   STEADY STATE: valid while every kv of the tile is visible to every query of the wave.  The reference stays where the last
+    //         general tile left it, O is only ever touched
+    //         by the accumulating MFMAs (a rescale branch inside one shared body made the compiler keep two copies of O: +64
+    //         VGPRs, 32..66 moves per tile), and there is NO row max at all: fp16 P holds 2^-24 .. 2^16 around the reference, i.e.
+    //         it only fails when a later score exceeds the first tile's row max by a factor e^11 - that is detected at the end
+    //         (inf / NaN in O or l) and the block redoes its rows with the general body on every tile.
+    //         Per tile that removes 28 max + 2 permlane swaps per q-block from an issue-bound loop.  (Pre-scaling Q by scale*log2 e
+    //         and starting the accumulators at -m_ref would also remove the 16 packed FMAs, but the extra fp16 rounding of q*c moves a
+    //         score by |s| * 2^-11 / sqrt(Dh): fine for |s| < 50, 9 % on p at the |s| ~ 2000 of the overflow test.)
+    // The unit of S / softmax / P.V work is a CHUNK of CH kv rows (CH = 64: the whole tile; CH = 32: half tiles).  With half tiles S
+    // and P of only 32 rows are live at a time, which is what lets a wave carry QB = 3 q-blocks (48 queries) in 256 VGPRs at
+    // Dh = 128: every K / V fragment read from LDS then feeds three MFMAs instead of two.  The loop is LDS-bandwidth bound (a
+    // fragment is 1 KB; at QB = 2 the LDS pipe needs as many cycles per tile as the MFMA pipe - tools/probes/probe_phases2/3.hip:
+    // 12.1 -> 10.0 ns per MFMA going from 2 to 3 MFMAs per fragment); on the real kernel: +6 % at 26 k tokens, but half tiles alone
+    // cost 3 % (shorter MFMA bursts) and 192-query blocks waste a quarter of a 577-token ViT sequence, so short sequences keep
+    // CH = 64 / QB = 2.
+    constexpr int NCH = KVT / CH, KVB = CH / 16, PC = CH / 32;
+    // nkvb: the first nkvb 16-row blocks of the chunk hold a key this wave can see (KVB in the steady state: folds away); the MFMAs,
+    // exponentials and P.V k-steps of the other blocks are skipped (ragged last tile: 577 = 9 x 64 + 1 keys per ViT frame; causal diagonal)
+    sc_f4 negm[QB];                               // PRE, steady state: (-m, -m, -m, -m) of every q-block = the C operand the score chains start from
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) negm[qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    auto s_part = [&](const char* sk, int c, sc_f4 (&s)[KVB][QB], int nkvb, auto steady) {
+        constexpr int NKF = KVB * DS;
+        const char* skc = sk + c * KVB * KBLK;
+        sc_h8 kfr[2];
+        kfr[0] = *reinterpret_cast<const sc_h8*>(skc + k_off[0]);
+#pragma unroll
+        for (int i = 0; i < NKF; ++i) {
+            const int kvb = i / DS, ds = i % DS;
+            if (i + 1 < NKF) kfr[(i + 1) & 1] = *reinterpret_cast<const sc_h8*>(skc + ((i + 1) / DS) * KBLK + k_off[(i + 1) % DS]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const sc_f4 acc = ds == 0 ? ((PRE && decltype(steady)::value) ? negm[qb] : sc_f4{0.f, 0.f, 0.f, 0.f}) : s[kvb][qb];
+                if (kvb < nkvb) s[kvb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[i & 1], qf[qb][ds], acc, 0, 0, 0);
+                else s[kvb][qb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto row_max = [&](const sc_f4 (&s)[KVB][QB], int qb) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kvb = 0; kvb < KVB; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kvb][qb][r]);
+        // max over the 4 lane groups holding this query column: two VALU row swaps (v_permlane16_swap / v_permlane32_swap with the
+        // value as both operands give x and its xor-16 / xor-32 partner) instead of two ~100-cycle ds_bpermute round trips
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) * (PRE ? 1.0f : scale_log2);      // scale > 0: max commutes with scaling
+    };
+    // P = 2^(s*scale - m) -> fp16 MFMA operand + row sums (one packed FMA per pair of scores)
+    // scalar fp32 math on purpose (the file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (and
+    // v_dot2_f32_f16) do not execute under an MFMA of the same SIMD - each costs ~11 cycles of the matrix pipe, while up to four
+    // plain v_fma_f32 / v_add_f32 per MFMA are free (tools/probes/probe_fat.hip, profiles/r02_run30_probe_fat.log)
+    auto p_part = [&](const sc_f4 (&s)[KVB][QB], int qb, float m_sub, sc_h8 (&pf)[QB][PC], int nkvb, auto steady) {
+        const float nm = -m_sub;
+        constexpr bool DIRECT = PRE && decltype(steady)::value;       // the reference is already inside s
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kvb = 0; kvb < KVB; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                float p0 = 0.f, p1 = 0.f;
+                if (kvb < nkvb) {
+                    p0 = __builtin_amdgcn_exp2f(DIRECT ? s[kvb][qb][r] : (PRE ? s[kvb][qb][r] + nm : __builtin_fmaf(s[kvb][qb][r], scale_log2, nm)));
+                    p1 = __builtin_amdgcn_exp2f(DIRECT ? s[kvb][qb][r + 1] : (PRE ? s[kvb][qb][r + 1] + nm : __builtin_fmaf(s[kvb][qb][r + 1], scale_log2, nm)));
+                }
+                if (!LSUM_MFMA) { ps0 += p0; ps1 += p1; }
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r] = (_Float16)p0;
+                pf[qb][kvb >> 1][(kvb & 1) * 4 + r + 1] = (_Float16)p1;
+            }
+        if (!LSUM_MFMA) l_run[qb] += ps0 + ps1;
+    };
+    auto pv_part = [&](const char* sv, int c, const sc_h8 (&pf)[QB][PC], int nkvb) {
+#pragma unroll
+        for (int pc = 0; pc < PC; ++pc) {
+            if (2 * pc >= nkvb) continue;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const char* vp = sv + (c * PC + pc) * 32 * VROW + v_off[db];
+                const sc_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp));
+                const sc_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s4*)(vp + 16 * VROW));
+                typedef short sc_s8 __attribute__((ext_vector_type(8)));
+                const sc_s8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const sc_h8 vf = __builtin_bit_cast(sc_h8, v8);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][pc], o[db][qb], 0, 0, 0);
+            }
+            if (LSUM_MFMA)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[qb][pc], ol[qb], 0, 0, 0);
+        }
+    };
+    auto masked = [&](int t) {
+        bool m = (t * KVT + KVT > kv_valid);
+        if (CAUSAL) m = m || (t * KVT + KVT - 1 > qw0 + coff);                        // wave-uniform
+        return m;
+    };
+
+    // pass 0: general tiles + the steady-state loop (no row max, no reference check: see the note above).  If any P of the block
+    // overflowed fp16 (a score more than 2^16 above its row's reference) O or l is inf / NaN at the end; the WHOLE block then
+    // redoes its rows in pass 1 with the general body only (exact online softmax on every chunk).
+    for (int pass = 0; pass < 2; ++pass) {
+        int t = t_lo;
+        while (t < t_hi) {
+            // ---------------- general tile ----------------
+            {
+                const int cur = (t - t_lo) & 1;
+                if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
+                const char* sk = smem + cur * STAGE;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (!wave_live) break;                                            // no valid query row in this wave: staging and barriers only
+                    int nkvb = (kv_valid - (t * KVT + c * CH) + 15) >> 4;                // 16-row blocks with a valid key ...
+                    if (CAUSAL) nkvb = min(nkvb, ((qw_last + coff - (t * KVT + c * CH)) >> 4) + 1);      // ... that the wave's last query still sees
+                    nkvb = max(0, min(nkvb, KVB));
+                    sc_f4 s[KVB][QB];
+                    s_part(sk, c, s, nkvb, std::false_type{});
+                    sc_h8 pf[QB][PC];
+                    const int kv_t0 = t * KVT + c * CH + g * 4;
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        const int qpos = qw0 + qb * 16 + rl + coff;
+#pragma unroll
+                        for (int kvb = 0; kvb < KVB; ++kvb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int kv = kv_t0 + kvb * 16 + r;
+                                const bool dead = (kv >= kv_valid) || (CAUSAL && kv > qpos);
+                                s[kvb][qb][r] = dead ? -INFINITY : s[kvb][qb][r];
+                            }
+                        const float m_new = fmaxf(m_run[qb], row_max(s, qb));
+                        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);       // 1 when the reference did not move, 0 at the start
+                        m_run[qb] = m_new;
+                        l_run[qb] *= alpha;
+                        if (LSUM_MFMA) ol[qb] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db) o[db][qb] *= alpha;
+                        p_part(s, qb, m_use, pf, nkvb, std::false_type{});
+                    }
+                    pv_part(sk + TILE, c, pf, nkvb);
+                }
+                __syncthreads();
+                ++t;
+            }
+            if (pass == 1) continue;
+            // ---------------- steady state ----------------
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) ok = ok && (m_run[qb] > -INFINITY);
+            if (!__all(ok)) continue;                                                 // a row without any visible key yet
+            if (PRE) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) negm[qb] = sc_f4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
+            }
+            while (t < t_hi && !masked(t)) {
+                const int cur = (t - t_lo) & 1;
+                if (t + 1 < t_hi) stage(cur ^ 1, t + 1);
+                const char* sk = smem + cur * STAGE;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    sc_f4 s[KVB][QB];
+                    s_part(sk, c, s, KVB, std::true_type{});
+                    sc_h8 pf[QB][PC];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) p_part(s, qb, m_run[qb], pf, KVB, std::true_type{});
+                    pv_part(sk + TILE, c, pf, KVB);
+                }
+                __syncthreads();
+                ++t;
+            }
+        }
+        if (pass == 1) break;
+        float chk = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            chk += (LSUM_MFMA ? ol[qb][0] : l_run[qb]) * 0.f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) chk += (o[db][qb][0] + o[db][qb][1] + o[db][qb][2] + o[db][qb][3]) * 0.f;        // inf, NaN -> NaN
+        }
+        if (!__syncthreads_or(chk != chk)) break;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int jj = 0; jj < QB; ++jj) o[i][jj] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; ol[qb] = sc_f4{0.f, 0.f, 0.f, 0.f}; }
+        if (t_lo < t_hi) stage(0, t_lo);
+        __syncthreads();
+    }
+
+    // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (LSUM_MFMA) l = ol[qb][0];
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qr = qw0 + qb * 16 + rl;
+        if (part) {            // split-KV partial: unnormalised O (fp32), running max (scaled log2 domain) and sum
+            if (qr < Sq) {
+                float* pp = part + ((((size_t)b * Hq + h) * Sq + qr) * nsplit + split) * (DH + 2);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) *reinterpret_cast<sc_f4*>(pp + db * 16 + g * 4) = o[db][qb];
+                if (g == 0) { pp[DH] = m_run[qb]; pp[DH + 1] = l; }
+            }
+        } else if (qr < Sq) {
+            _Float16* op = O + (size_t)b * (size_t)o_bs + (size_t)qr * (size_t)ldo + h * o_hs + g * 4;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const sc_h4 v = {(_Float16)(o[db][qb][0] * inv), (_Float16)(o[db][qb][1] * inv), (_Float16)(o[db][qb][2] * inv),
+                                 (_Float16)(o[db][qb][3] * inv)};
+                *reinterpret_cast<sc_h4*>(op + db * 16) = v;
+            }
+        }
+    }
+}
+
+// merge of the split-KV partials: out = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).  One workgroup (DH threads) per
+// (batch, head, query): the split weights are computed once by the first wave (one lane per split), then every thread owns one
+// output dimension and sums the weighted partials with independent loads.
+template <int DH>
+__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit, int o_hs, long o_bs) {
+    __shared__ float wgt[1024];
+    __shared__ float inv_den;
+    const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
+    const int q = row % Sq, bh = row / Sq, h = bh % Hq, b = bh / Hq;
+    const float* pp = part + (size_t)row * nsplit * (DH + 2);
+    // NW groups of DH threads walk the partials in an interleaved order, 8 independent loads in flight each: with a single group the
+    // kernel was one dependent load chain per output element (7.9 us for 128 partials: latency, not bytes).  The first batch of every
+    // thread is requested BEFORE the split weights are computed (they only multiply it): the two load latencies overlap instead of adding.
+    constexpr int NW = 1024 / DH < 8 ? 1024 / DH : 8;
+    __shared__ float red[NW][DH];
+    const int d = threadIdx.x % DH, w = threadIdx.x / DH;
+    float v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v0[u] = (w + u * NW < nsplit) ? pp[(w + u * NW) * (DH + 2) + d] : 0.f;
+    if (threadIdx.x < 64) {
+        float M = -INFINITY;
+        for (int i = threadIdx.x; i < nsplit; i += 64) M = fmaxf(M, pp[i * (DH + 2) + DH]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) M = fmaxf(M, __shfl_xor(M, s, 64));
+        float den = 0.f;
+        for (int i = threadIdx.x; i < nsplit; i += 64) {
+            const float m = pp[i * (DH + 2) + DH];
+            const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+            wgt[i] = w;
+            den += pp[i * (DH + 2) + DH + 1] * w;
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) den += __shfl_xor(den, s, 64);
+        if (threadIdx.x == 0) inv_den = den > 0.f ? 1.0f / den : 0.f;
+    }
+    __syncthreads();
+    float num = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (w + u * NW < nsplit) num += v0[u] * wgt[w + u * NW];
+    int i = w + 8 * NW;
+    for (; i + 7 * NW < nsplit; i += 8 * NW) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(i + u * NW) * (DH + 2) + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) num += v[u] * wgt[i + u * NW];
+    }
+    for (; i < nsplit; i += NW) num += pp[i * (DH + 2) + d] * wgt[i];
+    red[w][d] = num;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int u = 1; u < NW; ++u) num += red[u][d];
+        O[(size_t)b * (size_t)o_bs + (size_t)q * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decode attention (few query rows against a long KV cache; batch-1 decode packs the G query heads of a KV group as G <= 16 query
+// rows of one "head", llm.py _decode_one / DecodeGraph): HBM-bound, 2.8 GB of K/V per token at a 49 k context.  k_attn above serves
+// this shape with one workgroup per (head, split) in which only wave 0 has queries and ONE 64-row tile is in flight behind a block
+// barrier (4.4 TB/s).  Here every WAVE is an independent stream over its own contiguous run of 32-row chunks - no block barrier in
+// the loop - and keeps about three chunks (48 KB) in flight:
+//   K: straight from global memory into MFMA A-operand registers (a 16 x 32 fragment is 16 bytes per lane; each element is used
+//      once, so staging it in LDS would only add traffic), two register sets, re-issued as soon as the S MFMAs have consumed them;
+//   V: buffer_load ... lds into a per-wave ring of three 8 KiB stages (P.V needs V transposed: ds_read_b64_tr_b16), completion by a
+//      counted s_waitcnt vmcnt - the loads of a wave retire in order;
+//   rows past the wave's range are outside the buffer resource's extent: zeros, no memory traffic (the row part of every address
+//   stays in the VGPR offset, which is what the range check covers).
+// Exact online softmax per chunk (the loop is bandwidth-bound, the VALU work is free).  The four waves of a workgroup cover four
+// consecutive quarters of one split; they merge their (O, m, l) through LDS at the end, so a workgroup leaves ONE partial per split
+// in the layout k_attn_combine reads: half as many partials as before at the same number of waves streaming.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DCH = 32;                            // kv rows per chunk
+constexpr int DEC_STAGES = 2;
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+                                                        const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
+                                                        const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one V chunk (8 KiB at Dh = 128)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit, h = bh % Hq, b = bh / Hq;
+    const int hk = h / (Hq / Hkv);
+    const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
+    // chunks of this split, then of this wave
+    const int nch = (kv_valid + DCH - 1) / DCH, cps = (nch + nsplit - 1) / nsplit;
+    const int s_lo = min(split * cps, nch), s_hi = min(s_lo + cps, nch);
+    const int cpw = (s_hi - s_lo + 3) >> 2;
+    const int c_lo = min(s_lo + wave * cpw, s_hi), c_hi = min(c_lo + cpw, s_hi);
+    const int row_end = min(c_hi * DCH, kv_valid);                                      // rows of this wave: [c_lo * 32, row_end)
+
+    // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements)
+    sc_h8 qf[DS];
+    {
+        const int qr = rl < Sq ? rl : Sq - 1;
+        const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+    }
+    const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
+    const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
+    const int k_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldv + DH) * 2u) : 0;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kbase), 0, c_lo < c_hi ? k_ext : 0, 0x00020000);
+    // per-lane offsets inside a chunk: K fragment (kvb, ds) = row kvb*16 + rl, 16 bytes at element (ds*4 + g)*8;
+    // V granule j*64 + lane = row j*4 + (lane>>4), 16-byte slot (lane&15) ^ ((row&7)<<1)   (the swizzle the transpose reads below undo)
+    unsigned k_vo[2], v_vo[8];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) k_vo[kvb] = ((unsigned)(kvb * 16 + rl) * (unsigned)ldk + (unsigned)(g * 8)) * 2u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int vr = j * 4 + (lane >> 4); v_vo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)(((lane & 15) ^ ((vr & 7) << 1)) * 8)) * 2u; }
+    char* vring = smem + wave * (DEC_STAGES * CHB);
+    const unsigned vbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (DEC_STAGES * CHB));
+    const int vrow = 4 * g + (rl >> 2);
+    int v_off[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) v_off[db] = vrow * VROW + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+
+    auto issue = [&](int c, sc_u4 (&kr)[2][DS]) {              // 2*DS register loads + 8 LDS-DMA = 16 vm ops at Dh = 128, in this order
+        const unsigned ro_k = (unsigned)c * (unsigned)(DCH * ldk * 2), ro_v = (unsigned)c * (unsigned)(DCH * ldv * 2);
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) kr[kvb][ds] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (int)(ro_k + k_vo[kvb] + ds * 64), 0, 0);
+        char* dst = vring + (c % DEC_STAGES) * CHB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_load16(vbase, c < c_hi ? v_ext : 0, dst + j * 1024, ro_v + v_vo[j], 0);
+    };
+
+    sc_f4 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto compute = [&](int c, sc_u4 (&kr)[2][DS], auto reissue) {
+        // ---- S^T = K . Q^T for the 32 rows (this consumes the K registers) ----
+        sc_f4 s[2];
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb) {
+            s[kvb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) s[kvb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, kr[kvb][ds]), qf[ds], s[kvb], 0, 0, 0);
+        }
+        // the MFMAs above have READ kr; make that visible to the scheduler before the registers are loaded again
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        reissue();
+        // ---- exact online-softmax step ----
+        const int kv0 = c * DCH + g * 4;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kvb][r] = (kv0 + kvb * 16 + r < row_end) ? s[kvb][r] : -INFINITY;
+                tmax = fmaxf(tmax, s[kvb][r]);
+            }
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto bsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1])) * scale_log2;
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] *= alpha;
+        sc_h8 pf;
+        float ps = 0.f;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][r], scale_log2, -m_use));
+                ps += p;
+                pf[kvb * 4 + r] = (_Float16)p;
+            }
+        l_run += ps;
+        // ---- O^T += V^T . P^T : the V chunk must have landed (everything issued after it may stay in flight: 16 vm ops per chunk) ----
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DS + 8) : "memory");
+        // The transpose reads are inline asm: behind a builtin LDS read hipcc puts s_waitcnt vmcnt(0) (the LDS-DMA of later chunks "may
+        // alias" it), which would drain the whole prefetch queue on every chunk.  The stages of the ring are disjoint by construction.
+        const unsigned sa = vbase_lds + (unsigned)((c % DEC_STAGES) * CHB);
+        sc_s4 lo[DB], hi[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[db]) : "v"(sa + (unsigned)v_off[db]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[db]) : "v"(sa + (unsigned)v_off[db]), "n"(16 * VROW));
+        }
+        static_assert(DB == 8, "the lgkmcnt fence below names 16 registers");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
+                                              "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            typedef short sc_s8 __attribute__((ext_vector_type(8)));
+            const sc_s8 v8 = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi[db][0], hi[db][1], hi[db][2], hi[db][3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, v8), pf, o[db], 0, 0, 0);
+        }
+    };
+
+    // ---- the stream: chunks c_lo .. c_hi - 1; chunk c + 2 is requested right after the S MFMAs of chunk c ----
+    sc_u4 ka[2][DS], kb[2][DS];
+    if (c_lo < c_hi) {
+        issue(c_lo, ka);
+        issue(c_lo + 1, kb);                       // (past c_hi: zero extent -> no traffic)
+        for (int c = c_lo; c < c_hi; c += 2) {
+            compute(c, ka, [&] { issue(c + 2, ka); });
+            if (c + 1 < c_hi) compute(c + 1, kb, [&] { issue(c + 3, kb); });
+            else break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the ring is reused / the block ends
+    // ---- merge the four waves of the split through LDS (aliases the V rings: every wave is done with its own) ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* mo = reinterpret_cast<float*>(smem);             // [4][DH][16] O^T, then [4][16] m, [4][16] l
+    float* mm = mo + 4 * DH * 16;
+    float* ml = mm + 64;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[(wave * DH + db * 16 + g * 4 + r) * 16 + rl] = o[db][r];
+    if (g == 0) { mm[wave * 16 + rl] = m_run; ml[wave * 16 + rl] = l_run; }
+    __syncthreads();
+    for (int e = tid; e < Sq * DH; e += 256) {
+        const int q = e / DH, d = e - q * DH;
+        float M = fmaxf(fmaxf(mm[q], mm[16 + q]), fmaxf(mm[32 + q], mm[48 + q]));
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[w * 16 + q];
+            const float wt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+            acc += mo[(w * DH + d) * 16 + q] * wt;
+            l += ml[w * 16 + q] * wt;
+        }
+        float* pp = part + ((((size_t)b * Hq + h) * Sq + q) * nsplit + split) * (DH + 2);
+        pp[d] = acc;
+        if (d == 0) { pp[DH] = M; pp[DH + 1] = l; }
+    }
+}
+
+template <int DH, int QB, int CH = 64>
+int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Sq, int Skv,
+                int Hq, int Hkv, float scale, int causal, const int32_t* kv_len, float* part, int nsplit, int q_hs, int o_hs, long q_bs, long o_bs, hipStream_t s,
+                bool pre) {
+    const int nqb = (Sq + 4 * QB * 16 - 1) / (4 * QB * 16), G = Hq / Hkv;
+    const int npairs = nqb * Hkv * B;
+    const dim3 grid((unsigned)(((npairs + 7) / 8) * 8 * G * nsplit)), block(256);
+    const size_t lds = 2 * 2 * KVT * DH * 2;
+    const float sl2 = scale * 1.4426950408889634f;
+#define SC_LA(C, P) hipLaunchKernelGGL((k_attn<DH, QB, C, CH, P>), grid, block, lds, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk, (const _Float16*)v, \
+                                       ldv, (_Float16*)out, ldo, Sq, Skv, Hq, Hkv, sl2, kv_len, part, nsplit, B, q_hs, o_hs, q_bs, o_bs)
+    if (causal) { if (pre) SC_LA(true, true); else SC_LA(true, false); }
+    else { if (pre) SC_LA(false, true); else SC_LA(false, false); }
+#undef SC_LA
+    if (part) hipLaunchKernelGGL((k_attn_combine<DH>), dim3((unsigned)(B * Hq * Sq)), dim3(DH * (1024 / DH < 8 ? 1024 / DH : 8)), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
+    SC_CHECK_LAUNCH("sc_attention_f16");
+    return SC_OK;
+}
+
+}  // namespace
+
+static bool attn_decode_enabled() {
+    static const bool on = [] { const char* e = getenv("SC_ATTN_DECODE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+extern "C" int sc_attention_variant(int Dh, int Sq, int nsplit) {
+    if (Dh == 128 && nsplit == 1 && Sq >= 2048) return 1;
+    if (Dh == 128 && nsplit > 1 && Sq <= 16 && attn_decode_enabled()) return 3;      // (non-causal calls; a causal call of this shape runs k_attn)
+    return 0;
+}
+
+extern "C" int sc_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
+                                int Sq, int Skv, int Hq, int Hkv, int Dh, float scale, int causal_flags, const int32_t* kv_len,
+                                int nsplit, void* ws, size_t ws_bytes, int q_head_stride, int o_head_stride, int64_t q_batch_stride,
+                                int64_t o_batch_stride, sc_stream_t stream) {
+    SC_REQUIRE(q && k && v && out, "sc_attention_f16: null pointer argument");
+    SC_REQUIRE((causal_flags & ~(1 | SC_ATTN_Q_PRESCALED)) == 0, "sc_attention_f16: unknown bits in the causal / flags argument");
+    const int causal = causal_flags & 1;
+    SC_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "sc_attention_f16: bad sizes");
+    SC_REQUIRE(Dh == 64 || Dh == 128 || Dh == 32, "sc_attention_f16: head dim %d unsupported (32, 64, 128)", Dh);
+    SC_REQUIRE(!causal || Skv >= Sq, "sc_attention_f16: causal needs Skv >= Sq");
+    SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sc_attention_f16: leading dims must be multiples of 8 (out: 4)");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(out) & 7) == 0, "sc_attention_f16: q/k/v must be 16-byte aligned, out 8-byte");
+    hipStream_t s = (hipStream_t)stream;
+    SC_REQUIRE(nsplit >= 1 && nsplit <= 1024, "sc_attention_f16: nsplit must be in [1, 1024]");
+    float* part = nullptr;
+    if (nsplit > 1) {
+        const size_t need = (size_t)B * Hq * Sq * nsplit * (Dh + 2) * sizeof(float);
+        if (!ws || ws_bytes < need) return sc_fail(SC_ERR_WORKSPACE, "sc_attention_f16: split-KV workspace %zu < required %zu", ws_bytes, need);
+        part = (float*)ws;
+    }
+    const int qhs = q_head_stride > 0 ? q_head_stride : Dh, ohs = o_head_stride > 0 ? o_head_stride : Dh;
+    SC_REQUIRE(qhs % 8 == 0 && ohs % 4 == 0, "sc_attention_f16: head strides must be multiples of 8 (q) / 4 (out)");
+    const long qbs = q_batch_stride > 0 ? (long)q_batch_stride : (long)Sq * ldq, obs = o_batch_stride > 0 ? (long)o_batch_stride : (long)Sq * ldo;
+    SC_REQUIRE(qbs % 8 == 0 && obs % 4 == 0, "sc_attention_f16: batch strides must be multiples of 8 (q) / 4 (out)");
+    // few query rows against a long cache with split-KV = a decode step: the per-wave streaming kernel (SC_ATTN_DECODE=0: the tile kernel)
+    const bool pre = (causal_flags & SC_ATTN_Q_PRESCALED) != 0;
+    const float sl2_dec = pre ? 1.0f : scale * 1.4426950408889634f;
+    if (sc_attention_variant(Dh, Sq, nsplit) == 3 && !causal) {
+        constexpr int LDS_DEC = 4 * DEC_STAGES * DCH * 128 * 2;
+        static bool attr_done[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
+        hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)(B * Hq * nsplit)), dim3(256), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
+                           (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, sl2_dec, kv_len, part, nsplit, qhs, qbs);
+        hipLaunchKernelGGL((k_attn_combine<128>), dim3((unsigned)(B * Hq * Sq)), dim3(1024), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, ohs, obs);
+        SC_CHECK_LAUNCH("sc_attention_f16");
+        return SC_OK;
+    }
+    if (Dh == 64) return launch_attn<64, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    // long prefill: 48 queries per wave in half-tile chunks (three MFMAs per LDS fragment); everything else: 32 queries, whole tiles.
+    // (The hand-scheduled one-wave-per-SIMD k_attn_fat of round 2 kept the matrix pipe busier and delivered the same TFLOP/s under the
+    // board's power cap; it was removed in round 3 - see DESIGN.md section 4.)
+    if (sc_attention_variant(Dh, Sq, nsplit) == 1) return launch_attn<128, 3, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    if (Dh == 128) return launch_attn<128, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+    return launch_attn<32, 2>(q, ldq, k, ldk, v, ldv, out, ldo, B, Sq, Skv, Hq, Hkv, scale, causal, kv_len, part, nsplit, qhs, ohs, qbs, obs, s, pre);
+}

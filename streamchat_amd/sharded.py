@@ -220,7 +220,7 @@ class ShardedMemory:
         return views[0].clone() if len(views) == 1 else torch.cat(views, dim=0)
 
     # ---------------------------------------------------------------------------------------------
-    def broadcast_refs(self, refs, src=0, capacity=64):
+    def broadcast_refs(self, refs, src=0, capacity=None):
         """The root's retrieval decision (a list of Refs) to every rank as ONE small int64 tensor broadcast (no pickling):
         rows = (ref index, owner, kind, id, lo, hi); preceded by a one-element broadcast of the row count."""
         ctx = self.ctx
