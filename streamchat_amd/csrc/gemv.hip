@@ -7,6 +7,12 @@
 #include "sc_common.h"
 #include <stdlib.h>
 
+#ifndef SC_WPB_QKV
+#define SC_WPB_QKV 4
+#define SC_WPB_FEW 4
+#define SC_WPB_LONG 7          // down projection: 3584 rows, 2 per wave -> 256 workgroups of 7 waves = one per CU (+0.8 % tok/s; the others: +-0.2 %)
+#endif
+
 namespace {
 
 // Qwen2 RMSNorm of the activation vector, ONCE per workgroup, into LDS (fp16, HF's rounding: gamma * fp16(x * rstd)): the 256 threads
@@ -45,7 +51,7 @@ __device__ __forceinline__ void block_rmsnorm_to_lds(const _Float16* __restrict_
 }
 
 template <bool SWIGLU, bool OUT_F32, int RPW, int UNR = 4>
-__global__ __launch_bounds__(256) void k_gemv(      // 2 or 4 waves per workgroup (launcher's choice: whichever deals the rows evenly over the CUs)
+__global__ __launch_bounds__(512) void k_gemv(      // 2 or 4 waves per workgroup (launcher's choice: whichever deals the rows evenly over the CUs)
 const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
                                               const _Float16* __restrict__ res, void* __restrict__ y_base, int N, int K,
                                               const int* __restrict__ y_row, int y_ld, const _Float16* __restrict__ gamma, float eps) {
@@ -152,7 +158,7 @@ const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* 
 // pre-scaled for sc_attention_f16's SC_ATTN_Q_PRESCALED mode) on the fp32 accumulators + bias, rounded to fp16 ONCE - the numerics of
 // the prefill GEMM's rotary epilogue (gemm.hip) and of k_rope_f32in.
 template <bool TAB>
-__global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__ Wq, const _Float16* __restrict__ Wkv, const _Float16* __restrict__ bq,
+__global__ __launch_bounds__(512) void k_decode_qkv(const _Float16* __restrict__ Wq, const _Float16* __restrict__ Wkv, const _Float16* __restrict__ bq,
                                                     const _Float16* __restrict__ bkv, const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
                                                     float eps, _Float16* __restrict__ q_out, _Float16* __restrict__ cache, int ld,
                                                     const int* __restrict__ pos, int Hq, int Hkv, int Dh, int K, float log2_theta,
@@ -247,14 +253,21 @@ __global__ __launch_bounds__(256) void k_decode_qkv(const _Float16* __restrict__
     }
 }
 
-// Waves per workgroup.  4 everywhere.  (Round 3 tried to pick 2 / 3 / 4 per launch so that the workgroups deal evenly over the 256 CUs -
-// 576 workgroups are 3 on some CUs and 2 on others - and LOST: 299 vs 307 tok/s, profiles/r03_run9; the dispatcher balances by itself and
-// smaller workgroups repeat the norm more often.  SC_GEMV_WPB=2|3|4 still pins another count for experiments: block_rmsnorm_to_lds gives
-// the same bits for any of them.)
-int pick_wpb(int) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("SC_GEMV_WPB"); const int v = e ? atoi(e) : 0; forced = (v >= 2 && v <= 4) ? v : 4; }
-    return forced;
+// Waves per workgroup of the decode kernels, per kind of launch (0 q/k/v block, 1 short projection, 2 long rows / two rows per wave,
+// 3 everything else).  Every workgroup of these launches is resident at once, so a launch lasts as long as the CU with the most
+// workgroups: the counts below deal the 7B shapes evenly over 256 CUs where that measured faster (profiles/r03_run21_gemv_waves_per_block.md);
+// SC_GEMV_WPB_<kind>=n pins another count for experiments (block_rmsnorm_to_lds gives the same bits for any of them).
+int pick_wpb(int kind) {
+    static int forced[4] = {-1, -1, -1, -1};
+    static const int dflt[4] = {SC_WPB_QKV, SC_WPB_FEW, SC_WPB_LONG, 4};
+    if (forced[kind] < 0) {
+        char name[24];
+        snprintf(name, sizeof(name), "SC_GEMV_WPB_%d", kind);
+        const char* e = getenv(name);
+        const int v = e ? atoi(e) : 0;
+        forced[kind] = (v >= 1 && v <= 8) ? v : dflt[kind];
+    }
+    return forced[kind];
 }
 
 }  // namespace
@@ -268,7 +281,7 @@ extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
-    const int wpb = pick_wpb(ntask);
+    const int wpb = pick_wpb(0);
     hipLaunchKernelGGL(k_decode_qkv<false>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
                        cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta), (const float*)nullptr, (const float*)nullptr);
@@ -285,7 +298,7 @@ extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_tab_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
-    const int wpb = pick_wpb(ntask);
+    const int wpb = pick_wpb(0);
     hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
                        cache_ld, pos, q_heads, kv_heads, Dh, K, 0.f, tab_q, tab_k);
@@ -313,7 +326,7 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     // the tuning knob only applies where a kernel for that row count is instantiated (fp16 output); the fp32-output path of a short
     // projection always runs one row per wave, and the grid is derived from the rows per wave of the kernel actually launched
     const int rpw = few ? (out_f32 ? 1 : rpw_few) : 4;
-    const int wpb = pick_wpb((N + rpw - 1) / rpw), wpb2 = pick_wpb((N + 1) / 2);
+    const int wpb = pick_wpb(few ? 1 : 3), wpb2 = pick_wpb(2);
     const dim3 grid((unsigned)((N + wpb * rpw - 1) / (wpb * rpw))), block(64 * wpb);
     if (few && !out_f32 && (rpw == 2 || rpw == 4 || (rpw_few == 1 && K >= 8192))) {
         // long rows (the down projection, K = 18 944): two rows per wave and 8 x 16 B per lane in flight per row stream the 136 MB at
