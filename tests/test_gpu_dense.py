@@ -209,6 +209,41 @@ def test_gemv_vs_torch_fp32(N, K):
     torch.testing.assert_close(y32, w.float() @ x.float(), rtol=1e-3, atol=1e-3)
 
 
+def test_gemv_fused_rmsnorm_bits_do_not_depend_on_the_workgroup_size():
+    """block_rmsnorm_to_lds reduces in the order of 256 VIRTUAL threads whatever the workgroup size, so that kernels launched with
+    different wave counts (k_gemv: 4 waves, the down projection: 7, k_decode_qkv: 4; SC_GEMV_WPB_<kind> for experiments) normalise x to the
+    same bits - what keeps the eager decode step and the captured graph bit-identical.  The knob is read once per process: children."""
+    import hashlib
+    import subprocess
+    import sys
+    code = ("import torch, hashlib, tests.test_gpu_dense as T\n"
+            "from streamchat_amd import ops\n"
+            "w, x, g = T._rand((3584, 3584), 1, 3584 ** -0.5), T._rand((3584,), 2), (1 + T._rand((3584,), 3, 0.1).float()).half()\n"
+            "y = ops.gemv(w, x, None, rms_gamma=g, rms_eps=1e-6, out_f32=True)\n"
+            "print('HASH', hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for wpb in ("2", "3", "4", "7"):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SC_GEMV_WPB_1": wpb}, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([l.split()[1] for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert len(set(hashes)) == 1, hashes
+    w, x, g = _rand((3584, 3584), 1, 3584 ** -0.5), _rand((3584,), 2), (1 + _rand((3584,), 3, 0.1).float()).half()
+    y = ops.gemv(w, x, None, rms_gamma=g, rms_eps=1e-6, out_f32=True)
+    assert hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest() == hashes[0]
+    xn = (g.double() * (x.double() * torch.rsqrt((x.double() ** 2).mean() + 1e-6)).half().double()).half().double()
+    torch.testing.assert_close(y.double(), w.double() @ xn, rtol=1e-3, atol=1e-3)
+
+
+def test_decode_advance_bookkeeping():
+    nxt = torch.tensor([4242], dtype=torch.int64, device="cuda")
+    ring = torch.zeros(8, dtype=torch.int64, device="cuda")
+    cnt = torch.tensor([3], dtype=torch.int64, device="cuda")
+    tok, pos, ln, npv = (torch.tensor([v], dtype=torch.int32, device="cuda") for v in (7, 100, 101, 4))
+    ops.decode_advance(nxt, ring, cnt, tok, pos, ln, npv)
+    assert ring.tolist() == [0, 0, 0, 4242, 0, 0, 0, 0] and int(cnt) == 4 and (int(tok), int(pos), int(ln), int(npv)) == (4242, 101, 102, 5)
+
+
 def test_gemv_swiglu():
     K, I = 256, 384
     x = _rand((K,), 1)
