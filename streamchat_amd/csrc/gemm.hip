@@ -760,6 +760,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                     h4f(rr[mq][h], r4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (EPI == SC_EPI_COLSCALE ? (acc[mi][nj][e] + bv[h][e]) * cscale : epi_apply(acc[mi][nj][e] + bv[h][e], EPI)) + r4[e];
+                    // erf-GELU: keep the fp32 result a value of its own before the fp16 rounding - left alone hipcc fuses the last multiply-add
+                    // with the conversion (v_fma_mixlo_f16: ONE rounding), which k_gemm256 / k_gemm128 do not: a frame's features would then
+                    // depend on which kernel its micro-batch size selects (caught by the batching-independence tests)
+                    if (EPI == SC_EPI_GELU_ERF) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
                     (h ? hi : lo)[0] = pack2(v[0], v[1]);
                     (h ? hi : lo)[1] = pack2(v[2], v[3]);
                 }
