@@ -43,6 +43,21 @@ def test_abi_version_matches_header_and_changelog_names_every_symbol_added_since
         assert name in log and name in declared_symbols()
 
 
+def test_headed_gemm_says_unsupported_before_any_device_work(hip_lib):
+    """sc_gemm_headed_f16 serves the hand-scheduled kernel's shapes only and must say so (SC_ERR_UNSUPPORTED = -4) instead of computing
+    something else: argument and shape checks run before any launch, so this is callable without a GPU (the pointers are never touched)."""
+    from ctypes import c_float, c_void_p
+    p = c_void_p(4096)
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 384, 512, 384, 1024, 4, p, 0, 128, c_float(1.0), None)       # N = 384: not a multiple of 256
+    assert rc == -4 and b"N % 256" in hip_lib.sc_last_error()
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 7, p, 0, 128, c_float(1.0), None)       # unknown mode
+    assert rc == -1 and b"mode" in hip_lib.sc_last_error()
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 4, p, 0, 100, c_float(1.0), None)       # lead_cols not a head multiple
+    assert rc == -1
+    rc = hip_lib.sc_attention_f16(p, 128, p, 128, p, 128, p, 128, 1, 16, 16, 1, 1, 128, c_float(1.0), 8, None, 1, None, 0, 0, 0, 0, 0, None)   # unknown flag bit
+    assert rc == -1 and b"flags" in hip_lib.sc_last_error()
+
+
 def test_no_cpu_fallback():
     import pytest
     import torch
