@@ -145,24 +145,16 @@ class MMProjector:
         self.w2, self.b2 = _h(state_dict[prefix + "2.weight"], device), _h(state_dict[prefix + "2.bias"], device)
         self.d_out = self.w2.shape[0]
         self._mid = None
-        self._dense = None
 
     def __call__(self, hidden, n, P, drop_cls=True, out=None):
         M = n * P
         if self._mid is None or self._mid.shape[0] < M:
             self._mid = torch.empty((M, self.w0.shape[0]), dtype=torch.float16, device=hidden.device)
-        if drop_cls and n * P >= 1024 and hidden.shape[1] % 128 == 0:
-            # `feature_select` 'patch' (clip_encoder.py:53-58): the CLS rows are dropped by ONE strided copy (0.6 GB at 512 frames: 0.25 ms) so
-            # that the first projector GEMM runs on the hand-scheduled kernel (1.2 PF) instead of the row-mapped 8-wave fallback (0.71 PF:
-            # 3.1 ms per 512 frames, the last k_gemm256 launch of the step)
-            if self._dense is None or self._dense.shape[0] < M:
-                self._dense = torch.empty((M, hidden.shape[1]), dtype=torch.float16, device=hidden.device)
-            dense = self._dense[:M]
-            dense.view(n, P, -1).copy_(hidden.view(n, P + 1, -1)[:, 1:])
-            mid = ops.gemm(dense, self.w0, self.b0, epilogue="gelu", out=self._mid[:M])
-        else:
-            rows = (P, P + 1, 1) if drop_cls else None
-            mid = ops.gemm(hidden, self.w0, self.b0, epilogue="gelu", out=self._mid[:M], a_rows=rows, M=M)
+        # `feature_select` 'patch' (clip_encoder.py:53-58): the CLS rows are skipped by the GEMM's A row map (k_gemm256, 0.71 PF, 3.1 ms per 512
+        # frames).  Round 3 tried one strided copy + the hand-scheduled kernel instead: its erf-GELU epilogue (erff: ~40 VALU instructions per
+        # value, nothing to overlap them with at one wave per SIMD) ran 3.36 ms - slower; reverted (profiles/r03_bench_kernel_stats.md history).
+        rows = (P, P + 1, 1) if drop_cls else None
+        mid = ops.gemm(hidden, self.w0, self.b0, epilogue="gelu", out=self._mid[:M], a_rows=rows, M=M)
         return ops.gemm(mid, self.w2, self.b2, out=out)
 
 
