@@ -187,7 +187,10 @@ __global__ __launch_bounds__(512) void k_decode_qkv(const _Float16* __restrict__
     // RMSNorm of x once per workgroup into LDS; the first four K-slices of both weight rows are requested before it (see k_gemv)
     extern __shared__ __attribute__((aligned(16))) char qkv_smem[];
     _Float16* xn = reinterpret_cast<_Float16*>(qkv_smem);
-    constexpr int PF = 4;
+#ifndef SC_QKV_PF
+#define SC_QKV_PF 4
+#endif
+    constexpr int PF = SC_QKV_PF;                  // K-slices of both rows requested before the norm (8 = the whole row at K <= 4096)
     sc_h8 pa[PF], pb[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
