@@ -144,6 +144,14 @@ def _sharded(ctx):
         srows = sum(r.rows for r in wanted[:n_short])
         out.append(dict(tree=_describe(tree), short=None if sel is None else sel[:srows], path=None if sel is None else sel[srows:],
                         texts=texts, merged=merged, wanted=[mem.frames_of(r) for r in wanted]))
+        if seg == len(SEGMENTS) - 1 and ctx.world > 1:
+            # a fetched block must stay valid when the next fetch reuses the persistent receive buffer (single-piece results
+            # used to be views of it)
+            leafs = [nd.centroids for nd in tree if nd.depth == 0][-2:]
+            x = mem.fetch([leafs[0]], dst=0, mode="allgather")
+            keep = None if x is None else x.clone()
+            mem.fetch([leafs[1]], dst=0, mode="allgather")
+            assert x is None or torch.equal(x, keep), "an earlier fetch result was overwritten by the next fetch"
     return out
 
 
