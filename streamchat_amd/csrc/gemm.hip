@@ -528,6 +528,15 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 // with the accumulator tied in place, asm fragment reads, explicit waits, DMA rounds spread one per 7 MFMAs); what that bought, what
 // it needed (whole 128-byte lines per DMA pair, no bursts) and the hazards it runs into are written up in DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef FAT_TRACE
+// diagnostic build only (tools/trace_fat.py): per workgroup and tile the 100 MHz timestamps of tile start / end of the K loop / end of the epilogue
+#define FAT_TRACE_TILES 96
+__device__ unsigned long long g_fat_trace[256 * FAT_TRACE_TILES * 3];
+extern "C" int sc_fat_trace_read(void* dst, size_t bytes) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fat_trace), bytes) == hipSuccess ? 0 : 1; }
+#define FAT_STAMP(slot) do { if (tid == 0 && tcount < FAT_TRACE_TILES && blockIdx.x < 256) g_fat_trace[(blockIdx.x * FAT_TRACE_TILES + tcount) * 3 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FAT_STAMP(slot)
+#endif
 template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // One DMA instruction moves 64 rows x 64 B of one plane; the two planes of the same rows are issued back to back, so both
     // halves of every 128-byte line of the operand are consumed while the line is in flight / in the L1 (fetching the halves a
     // K-step apart, as with K = 32 stages, costs twice the L2 -> L1 line traffic).
-    constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB, BIAS_OFF = 2 * BUF;        // + 8 KiB of bias slots behind the two buffers
+    constexpr int PL = 256 * 64, OPB = 2 * PL, BUF = 2 * OPB, SLAB_OFF = 2 * BUF;        // + 8 KiB per wave behind the two buffers: epilogue slabs (below)
     const int dr = tid >> 2, dc = (tid & 3) ^ swzF(tid >> 4);
     // buffer resources are rebased per tile (base = first row of the tile, extent = its valid rows), so operands of any size work
     // with 32-bit offsets and rows past M / N read as zeros; the four 64-row groups of a DMA round set get their own lane offsets
@@ -674,13 +683,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         }
     };
     for (;;) {                                                  // tiles of this workgroup (one unless PERSIST)
-    // The tile's bias goes to LDS by DMA now (each wave its own 128 columns, 1 KiB slot per wave and tile parity; lanes >= 16 and a
-    // null bias are out of range -> zeros): a vector load in the epilogue would make hipcc wait (vmcnt is in order) for the DMA
-    // prefetch of the next tile and for the C stores issued before it.  The wait at RC of iteration 0 covers this DMA.
+    // The tile's bias goes to LDS by DMA now (each wave its own 128 columns into the first KiB of its residual slab, which is idle
+    // during the K loop; lanes >= 16 and a null bias are out of range -> zeros): a vector load in the epilogue would make hipcc wait
+    // (vmcnt is in order) for the DMA prefetch of the next tile and for the C stores issued before it.  The wait at RC of iteration 0
+    // covers this DMA; the previous tile's epilogue has consumed everything it read from the slab.
     {
         const int n0b = __builtin_amdgcn_readfirstlane(tn * BN2 + wc * 128);
-        lds_load16(bias ? bias + n0b : W, bias ? 256u : 0u, smem + BIAS_OFF + ((tcount & 1) * 4 + wave) * 1024, (unsigned)lane * 16u, 0u);
+        lds_load16(bias ? bias + n0b : W, bias ? 256u : 0u, smem + SLAB_OFF + wave * 8192 + 4096, (unsigned)lane * 16u, 0u);
     }
+    FAT_STAMP(0);
     iter(std::integral_constant<int, 0>{}, std::true_type{}, 0);    // (writes every accumulator: nothing to zero)
     iter(std::integral_constant<int, 1>{}, std::false_type{}, 1);
     for (int k = 2; k < nk; k += 2) {                           // nk is even (dispatch)
@@ -690,6 +701,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     // the asm MFMAs are invisible to the hazard recognizer: drain before reading acc
     // after the last tile: the (zero-fill) DMA rounds of the last two iterations must not land in the LDS of the workgroup that
     // follows this one on the CU
+    FAT_STAMP(1);
     if (!has_nx) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: lane owns C[m0 + mi*16 + rl][n0 + nj*16 + g*4 .. +3], 8 x 8 tiles per wave.  Bias, residual and the stores
@@ -710,80 +722,121 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         f[0] = (float)lo[0]; f[1] = (float)lo[1]; f[2] = (float)hi[0]; f[3] = (float)hi[1];
     };
     _Float16* Ch = reinterpret_cast<_Float16*>(Cout);
-    const char* bslot = smem + BIAS_OFF + ((tcount & 1) * 4 + wave) * 1024 + g_e * 8;         // + nj * 32: this lane's 4 bias values
+    // Epilogue slabs, per wave 8 KiB behind the K buffers (2 x 64 KiB + 4 x 8 KiB = all 160 KiB of the CU): a 4-KiB C slab and a 4-KiB
+    // residual slab whose first KiB receives the tile's bias during the K loop.  The accumulator layout (lane = row rl, 4 columns) is
+    // the wrong shape for global memory - adjacent lanes are adjacent ROWS, so a store or load in that layout is 64 separate 8 / 16-byte
+    // requests (measured with tools/trace_fat.py: 2 us of a 5-6 us epilogue for the half-line stores, 8 us for the residual loads).  One
+    // step = one 16-row tile x the wave's columns: fp16 results are written to the C slab in the accumulator layout and read back along
+    // rows, so every store instruction writes whole 128-byte lines (4 rows x 256 B); residual rows arrive the same way (row-major
+    // 16-byte loads -> residual slab -> 8-byte reads in the accumulator layout; added in fp32 before the one rounding, as always).
+    // Slab rows are 256 B, 16-byte chunk c of row r at c ^ r: conflict-free for both access shapes.
+    char* const cslab = smem + SLAB_OFF + wave * 8192;
+    char* const rslab = cslab + 4096;
+    const char* bslot = rslab + g_e * 8;                                            // + nj * 32: this lane's 4 bias values
     if (EPI == SC_EPI_SWIGLU) {
+        // 64 output columns per wave: slab rows are 128 B (two per bank row), chunk c of row r at c ^ (r >> 1); one store = 8 rows x 128 B
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + (n0 >> 1), rv * ldc * 2);
+        const int srow = g_e * 2 + (rl_e >> 3), sch = rl_e & 7;                     // row-major view: lane -> row srow (+ 8), chunk sch
+        char* cw = cslab + rl_e * 128 + g_e * 4;                                    // + ((nj ^ (rl >> 1)) << 4)
+        const char* cr = cslab + srow * 128 + ((sch ^ (srow >> 1)) << 4);           // second half: + 1024, chunk ^ 4
+        const char* cr1 = cslab + (srow + 8) * 128 + ((sch ^ ((srow + 8) >> 1)) << 4);
+        int st_vo = (srow * ldc + sch * 8) * 2, rstep8_c = 16 * ldc;
+        asm volatile("" : "+v"(st_vo), "+v"(rstep8_c));
+        const int swz = rl_e >> 1;
+        float bv[8][4];
 #pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {                        // two groups of four 16-column tiles -> 32 output columns each
-            float bv[4][4];
+        for (int nj = 0; nj < 8; ++nj) h4f(*reinterpret_cast<const sc_u2*>(bslot + nj * 32), bv[nj]);
+        auto smath = [&](int mi) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) h4f(*reinterpret_cast<const sc_u2*>(bslot + (q4 * 4 + nj) * 32), bv[nj]);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                unsigned d[4];
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    const sc_f4 c = acc[mi][q4 * 4 + nj];
-                    const float g0 = c[0] + bv[nj][0], g1 = c[1] + bv[nj][1], u0 = c[2] + bv[nj][2], u1 = c[3] + bv[nj][3];
-                    d[nj] = pack2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
-                }
-                const auto p0 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
-                const auto p1 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
-                const auto q0 = __builtin_amdgcn_permlane32_swap(p0[0], p1[0], false, false);
-                const auto q1 = __builtin_amdgcn_permlane32_swap(p0[1], p1[1], false, false);
-                unsigned w0 = q0[0], w1 = q1[0], w2 = q0[1], w3 = q1[1];
-                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl_e * ldc + g_e * 8) * 2 + mi * rstep_c, q4 * 64, 0);
-                asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));      // see the note at the other store below
+            for (int nj = 0; nj < 8; ++nj) {
+                const sc_f4 c = acc[mi][nj];
+                const float g0 = c[0] + bv[nj][0], g1 = c[1] + bv[nj][1], u0 = c[2] + bv[nj][2], u1 = c[3] + bv[nj][3];
+                *reinterpret_cast<unsigned*>(cw + ((nj ^ swz) << 4)) = pack2(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0)) * u0, g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1)) * u1);
             }
+        };
+        auto sslab = [&](sc_u4 (&d)[2]) {
+            d[0] = *reinterpret_cast<const sc_u4*>(cr);
+            d[1] = *reinterpret_cast<const sc_u4*>(cr1);
+        };
+        auto sstore = [&](int mi, const sc_u4 (&d)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned w0 = d[i][0], w1 = d[i][1], w2 = d[i][2], w3 = d[i][3];      // (store / s_nop pairing: see the note in cstore below)
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, st_vo + mi * rstep_c + i * rstep8_c, 0, 0);
+                asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+            }
+        };
+        sc_u4 d[2];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            smath(mi);
+            if (mi > 0) sstore(mi - 1, d);
+            sslab(d);
         }
+        sstore(7, d);
     } else {
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
         const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
         // SC_EPI_COLSCALE: the wave's 128 columns are scaled if they lie in [0, lead_cols) (the query third of a fused q|k|v projection
         // carries the softmax scale * log2 e into sc_attention_f16's pre-scaled mode: applied to the fp32 sum, ONE rounding)
         const float cscale = (EPI == SC_EPI_COLSCALE && n0 < lead_cols) ? col_scale : 1.0f;
-        // one step = a column pair (two 16-column tiles) x four row tiles: bias + activation + residual, 16-byte stores
-        auto step = [&](int st, const sc_u2 (&rr)[4][2]) {
-            const int pr = st >> 1, mh = st & 1;
+        // slab offsets of this lane: accumulator layout (8 bytes of row rl, column tile nj: XOR nj * 32 into the offset) and row-major
+        // view (16 bytes of row g + 4 i at chunk rl: + i * 1024 after XORing i * 64)
+        const int acc_o = rl_e * 256 + ((((g_e >> 1) ^ rl_e) & 15) << 4) + (g_e & 1) * 8;
+        const int row_o = g_e * 256 + (((rl_e ^ g_e) & 15) << 4);
+        int st_vo = (g_e * ldc + rl_e * 8) * 2, rstep4_c = 8 * ldc, ld_vo = (g_e * ldr + rl_e * 8) * 2, rstep4_r = 8 * ldr;
+        asm volatile("" : "+v"(st_vo), "+v"(rstep4_c), "+v"(ld_vo), "+v"(rstep4_r));
+        auto cmath = [&](int mi, const float (&bv)[8][4], const sc_u2 (&rr)[8], bool has_r) {   // math of row tile mi -> C slab (LDS runs a wave's accesses in order: these writes stay behind the slab reads of tile mi - 1)
             __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: hipcc otherwise pulls all accumulator reads up front and spills
-            float bv[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) h4f(*reinterpret_cast<const sc_u2*>(bslot + (2 * pr + h) * 32), bv[h]);
+            for (int nj = 0; nj < 8; ++nj) {
+                float v[4];
 #pragma unroll
-            for (int mq = 0; mq < 4; ++mq) {
-                const int mi = mh * 4 + mq;
-                unsigned lo[2], hi[2];
+                for (int e = 0; e < 4; ++e) v[e] = EPI == SC_EPI_COLSCALE ? (acc[mi][nj][e] + bv[nj][e]) * cscale : epi_apply(acc[mi][nj][e] + bv[nj][e], EPI);
+                if (has_r) {
+                    float r4[4];
+                    h4f(rr[nj], r4);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int nj = 2 * pr + h;
-                    float v[4], r4[4];
-                    h4f(rr[mq][h], r4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (EPI == SC_EPI_COLSCALE ? (acc[mi][nj][e] + bv[h][e]) * cscale : epi_apply(acc[mi][nj][e] + bv[h][e], EPI)) + r4[e];
-                    // erf-GELU: keep the fp32 result a value of its own before the fp16 rounding - left alone hipcc fuses the last multiply-add
-                    // with the conversion (v_fma_mixlo_f16: ONE rounding), which k_gemm256 / k_gemm128 do not: a frame's features would then
-                    // depend on which kernel its micro-batch size selects (caught by the batching-independence tests)
-                    if (EPI == SC_EPI_GELU_ERF) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-                    (h ? hi : lo)[0] = pack2(v[0], v[1]);
-                    (h ? hi : lo)[1] = pack2(v[2], v[3]);
+                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
                 }
-                const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-                // gfx950: a VALU write to the data registers of a 16-byte buffer store (scalar offset form) in the very next instruction
-                // corrupts the stored value (seen as garbage in lanes 12..15 of each row of 16; profiles/r01_run161) and hipcc does not
-                // guard it: the asm keeps the four registers allocated past the store and puts wait states before any reuse
-                unsigned w0 = s0[0], w1 = s1[0], w2 = s0[1], w3 = s1[1];
-                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, (rl_e * ldc + (g_e & 1) * 16 + (g_e >> 1) * 8) * 2 + mi * rstep_c, 2 * pr * 32, 0);
+                // erf-GELU: keep the fp32 result a value of its own before the fp16 rounding - left alone hipcc fuses the last multiply-add
+                // with the conversion (v_fma_mixlo_f16: ONE rounding), which k_gemm256 / k_gemm128 do not: a frame's features would then
+                // depend on which kernel its micro-batch size selects (caught by the batching-independence tests)
+                if (EPI == SC_EPI_GELU_ERF) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                *reinterpret_cast<sc_u2*>(cslab + (acc_o ^ (nj * 32))) = sc_u2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        };
+        auto cslab_rd = [&](sc_u4 (&d)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const sc_u4*>(cslab + (row_o ^ (i * 64)) + i * 1024);
+        };
+        auto cstore = [&](int mi, const sc_u4 (&d)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // gfx950: a VALU write to the data registers of a 16-byte buffer store in the very next instruction corrupts the stored
+                // value (profiles/r01_run161) and hipcc does not guard it: the asm keeps the four registers allocated past the store
+                unsigned w0 = d[i][0], w1 = d[i][1], w2 = d[i][2], w3 = d[i][3];
+#if !(defined(FAT_EPI_ABL) && (FAT_EPI_ABL & 1))
+                __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, st_vo + mi * rstep_c + i * rstep4_c, 0, 0);
+#endif
                 asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
             }
         };
-        auto load_res = [&](int st, sc_u2 (&rr)[4][2]) {
-            const int pr = st >> 1, mh = st & 1;
+        auto load_res = [&](int mi, sc_u4 (&rg)[4]) {            // residual rows of row tile mi, row-major (4 rows x 256 B per instruction)
 #pragma unroll
-            for (int mq = 0; mq < 4; ++mq)
+            for (int i = 0; i < 4; ++i)
+#if defined(FAT_EPI_ABL) && (FAT_EPI_ABL & 2)
+                rg[i] = sc_u4{(unsigned)mi, (unsigned)i, 0u, 0u};
+#else
+                rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ld_vo + mi * rstep_r + i * rstep4_r, 0, 0);
+#endif
+        };
+        auto rslab_rw = [&](const sc_u4 (&rg)[4], sc_u2 (&rr)[8]) {  // -> this lane's residual values in the accumulator layout
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    rr[mq][h] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rl_e * ldr + g_e * 4) * 2 + (mh * 4 + mq) * rstep_r, (2 * pr + h) * 32, 0);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<sc_u4*>(rslab + (row_o ^ (i * 64)) + i * 1024) = rg[i];
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj) rr[nj] = *reinterpret_cast<const sc_u2*>(rslab + (acc_o ^ (nj * 32)));
         };
         if (EPI == SC_EPI_ROPE && n0 < lead_cols) {
             // Rotary epilogue (Qwen2 q / k projections): the wave's 128 columns are ONE head; rotate-half pairs column j with j + 64, i.e.
@@ -844,25 +897,51 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 rstep(st + 1, cb, sb);
             }
         } else if (R) {
-            // the residual of step st + 1 is requested BEFORE the stores of step st are issued: vmcnt retires in order, so a load issued
-            // behind stores could only be consumed after those stores have completed (write latency exposed on every step)
-            sc_u2 ra[4][2], rb[4][2];
-            load_res(0, ra);
+            // (the bias values are made opaque on each side of this branch: hipcc otherwise hoists the `acc + bias` adds common to both
+            // sides above the branch and parks the sums in AGPRs and scratch)
+            // residual rows are requested three row tiles ahead, and before the stores of the step in between (vmcnt retires in order: a
+            // load issued behind stores could only be consumed after those stores have completed)
+            float bv[8][4];
 #pragma unroll
-            for (int st = 0; st < 8; st += 2) {
-                load_res(st + 1, rb); step(st, ra);
-                if (st + 2 < 8) load_res(st + 2, ra);
-                step(st + 1, rb);
+            for (int nj = 0; nj < 8; ++nj) {
+                h4f(*reinterpret_cast<const sc_u2*>(bslot + nj * 32), bv[nj]);
+                asm volatile("" : "+v"(bv[nj][0]), "+v"(bv[nj][1]), "+v"(bv[nj][2]), "+v"(bv[nj][3]));     // see the note at the branch
+            }
+            sc_u4 rg[3][4];
+            sc_u2 rr[8];
+            load_res(0, rg[0]); load_res(1, rg[1]); load_res(2, rg[2]);
+            rslab_rw(rg[0], rr);                                  // (after the bias reads: the slab's first KiB held the bias)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                // (the stores are not deferred by a step here - the residual slab traffic of the next row tile covers most of the C slab's
+                // read latency, and 16 registers fewer are live across the math: this side of the branch is the tight one)
+                cmath(mi, bv, rr, true);
+                if (mi + 3 < 8) load_res(mi + 3, rg[mi % 3]);
+                sc_u4 d[4];
+                cslab_rd(d);
+                if (mi + 1 < 8) rslab_rw(rg[(mi + 1) % 3], rr);
+                cstore(mi, d);
             }
         } else {
-            sc_u2 rz[4][2];
+            float bv[8][4];
 #pragma unroll
-            for (int mq = 0; mq < 4; ++mq) { rz[mq][0] = sc_u2{0u, 0u}; rz[mq][1] = sc_u2{0u, 0u}; }
+            for (int nj = 0; nj < 8; ++nj) {
+                h4f(*reinterpret_cast<const sc_u2*>(bslot + nj * 32), bv[nj]);
+                asm volatile("" : "+v"(bv[nj][0]), "+v"(bv[nj][1]), "+v"(bv[nj][2]), "+v"(bv[nj][3]));     // see the note at the branch
+            }
+            sc_u2 rz[8] = {};
+            sc_u4 d[4];
 #pragma unroll
-            for (int st = 0; st < 8; ++st) step(st, rz);
+            for (int mi = 0; mi < 8; ++mi) {
+                cmath(mi, bv, rz, false);
+                if (mi > 0) cstore(mi - 1, d);
+                cslab_rd(d);
+            }
+            cstore(7, d);
         }
     }
     }
+    FAT_STAMP(2);
     ++tcount;
     if (!has_nx) break;
     vb += (int)gridDim.x;
@@ -1017,12 +1096,12 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             const bool fp = persist && fat != 2 && nt_all > n_cu;
             static bool fattr[16][8][2] = {};
             if (!fattr[dev][EPI][fp]) {
-                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
+                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
                 fattr[dev][EPI][fp] = true;
             }
-            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                        (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
-            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                     (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
@@ -1077,12 +1156,12 @@ int launch_headed(const void* A, int lda, const void* W, const void* bias, void*
     const int gm_sel = tN > 16 ? 4 : SC_GEMM_GM;
     static bool attr[16][2] = {};
     if (!attr[dev][fp]) {
-        (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
+        (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr[dev][fp] = true;
     }
-    if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+    if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                                (const _Float16*)nullptr, 0, C, ldc, M, N, K, tN, gm_sel, nt_all, tab, pos0, lead_cols, col_scale);
-    else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), dim3((unsigned)nt_all), dim3(256), 131072 + 8192, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
+    else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), dim3((unsigned)nt_all), dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
                             (const _Float16*)nullptr, 0, C, ldc, M, N, K, tN, gm_sel, nt_all, tab, pos0, lead_cols, col_scale);
     SC_CHECK_LAUNCH("sc_gemm_headed_f16");
     return SC_OK;
