@@ -512,6 +512,8 @@ def main():
         tmax = torch.tensor([dt, t_enc], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, t_enc = float(tmax[0].item()), float(tmax[1].item())
+        dist.barrier()
+        dist.destroy_process_group()                      # the last collective: ranks > 0 leave now, rank 0 goes on to format the record alone
     if rank != 0:
         return
     ms_step = dt / a.steps * 1e3
