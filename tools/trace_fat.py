@@ -12,7 +12,7 @@ import torch
 from streamchat_amd import ops, _lib
 
 SHAPES = {"vit512.qkv+b": (512 * 577, 3072, 1024), "vit512.o+res": (512 * 577, 1024, 1024), "vit512.fc1+gelu": (512 * 577, 4096, 1024),
-          "vit512.fc2+res": (512 * 577, 1024, 4096), "llm49k.q": (48994, 3584, 3584), "llm49k.down": (48994, 3584, 18944), "llm49k.o+res": (48994, 3584, 3584)}
+          "vit512.fc2+res": (512 * 577, 1024, 4096), "llm49k.q": (48994, 3584, 3584), "llm49k.down": (48994, 3584, 18944), "llm49k.o+res": (48994, 3584, 3584), "llm49k.gateup+swiglu": (48994, 37888, 3584)}
 TILES = 96
 lib = _lib.load()
 lib.sc_fat_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -22,10 +22,10 @@ for name in (sys.argv[1:] or list(SHAPES)):
     M, N, K = SHAPES[name]
     a = (torch.rand(M, K, device="cuda") * 2 - 1).half()
     w = (torch.rand(N, K, device="cuda") * 2 - 1).half()
-    epi = "quick_gelu" if "+gelu" in name else "none"
+    epi = "quick_gelu" if "+gelu" in name else ("swiglu" if "+swiglu" in name else "none")
     bias = (torch.rand(N, device="cuda") - 0.5).half() if "+" in name else None
     res = (torch.rand(M, N, device="cuda") - 0.5).half() if "+res" in name else None
-    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    out = torch.empty(M, N // 2 if epi == "swiglu" else N, device="cuda", dtype=torch.float16)
     for _ in range(4):
         ops.gemm(a, w, bias, res, epi, out=out)
     torch.cuda.synchronize()
