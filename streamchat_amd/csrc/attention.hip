@@ -392,6 +392,13 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
     }
 
     // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----
+    // In this layout adjacent lanes are adjacent QUERY ROWS: an 8-byte store per lane is 64 separate requests (8 % of the ViT launch,
+    // profiles/r03_run40).  When the output rows allow 16-byte stores the fp16 tile goes through LDS instead (the K / V stages are free
+    // now; each wave its own slab, rows padded by 16 B) and leaves along rows: 64 / (DH / 8) rows of DH * 2 bytes per instruction.
+    const bool rows16 = !part && (((unsigned)ldo | (unsigned)o_hs | (unsigned)(o_bs & 0xffff)) & 7u) == 0 && (reinterpret_cast<size_t>(O) & 15) == 0;
+    constexpr int ORS = DH * 2 + 16;              // slab row stride
+    static_assert(4 * QB * 16 * ORS <= 2 * STAGE, "the output slabs must fit in the K / V stages");
+    if (rows16) __syncthreads();                  // every wave is done with the last tile's K / V fragments
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         float l = l_run[qb];
@@ -406,6 +413,22 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 #pragma unroll
                 for (int db = 0; db < DB; ++db) *reinterpret_cast<sc_f4*>(pp + db * 16 + g * 4) = o[db][qb];
                 if (g == 0) { pp[DH] = m_run[qb]; pp[DH + 1] = l; }
+            }
+        } else if (rows16) {
+            char* slab = smem + (wave * QB + qb) * 16 * ORS;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const sc_h4 v = {(_Float16)(o[db][qb][0] * inv), (_Float16)(o[db][qb][1] * inv), (_Float16)(o[db][qb][2] * inv),
+                                 (_Float16)(o[db][qb][3] * inv)};
+                *reinterpret_cast<sc_h4*>(slab + rl * ORS + db * 32 + g * 8) = v;
+            }
+            constexpr int CPR = DH / 8, RPI = 64 / CPR;               // 16-byte chunks per row, rows per store instruction
+            const int sr = lane / CPR, sc = lane % CPR;
+#pragma unroll
+            for (int i = 0; i < 16 / RPI; ++i) {
+                const int row = i * RPI + sr, qrow = qw0 + qb * 16 + row;
+                const sc_u4 d = *reinterpret_cast<const sc_u4*>(slab + row * ORS + sc * 16);          // (same wave wrote it: LDS keeps a wave's accesses in order)
+                if (qrow < Sq) *reinterpret_cast<sc_u4*>(O + (size_t)b * (size_t)o_bs + (size_t)qrow * (size_t)ldo + h * o_hs + sc * 8) = d;
             }
         } else if (qr < Sq) {
             _Float16* op = O + (size_t)b * (size_t)o_bs + (size_t)qr * (size_t)ldo + h * o_hs + g * 4;
