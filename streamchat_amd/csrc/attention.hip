@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 2 : 3)) void k_attn(const _Float1
 
     // ---- normalise + store: lane holds O[q][db*16 + g*4 .. +3] ----
     // In this layout adjacent lanes are adjacent QUERY ROWS: an 8-byte store per lane is 64 separate requests (8 % of the ViT launch,
-    // profiles/r03_run40).  When the output rows allow 16-byte stores the fp16 tile goes through LDS instead (the K / V stages are free
+    // profiles/r03_run39_40_attn_output_store.md).  When the output rows allow 16-byte stores the fp16 tile goes through LDS instead (the K / V stages are free
     // now; each wave its own slab, rows padded by 16 B) and leaves along rows: 64 / (DH / 8) rows of DH * 2 bytes per instruction.
     const bool rows16 = !part && (((unsigned)ldo | (unsigned)o_hs | (unsigned)(o_bs & 0xffff)) & 7u) == 0 && (reinterpret_cast<size_t>(O) & 15) == 0;
     constexpr int ORS = DH * 2 + 16;              // slab row stride
