@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         constexpr int X = decltype(Xc)::value;
         constexpr bool FIRST = decltype(Fc)::value;
         const int fin = (k + 1 >= nk) ? 1 : 0;
-        const int relax = (PERSIST && k == 0 && tcount > 0) ? 1 : 0;       // stores of the previous tile's epilogue may still be in flight
+        const int relax = (PERSIST && k == 0 && tcount > 0) ? (R && EPI != SC_EPI_SWIGLU ? 2 : 1) : 0;       // stores of the previous tile's epilogue may still be in flight
         // s_nop: the accumulators are zeroed by VALU writes in the loop preheader and the hazard recognizer does not know that the asm
         // below reads them as MFMA SrcC; everything after this statement is in the loop body, so three wait states are guaranteed
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
@@ -662,8 +662,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
             if (t == RC) {
                 // iteration k + 1 (issued one iteration ago) has landed when at most the DMA rounds of this iteration are in flight; in
                 // the first iteration after an epilogue its C stores (younger than that DMA, same in-order counter) may stay in flight too
-                if (X == 0) asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\ts_cbranch_vccz .Lfat_w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lfat_x%=\n.Lfat_w%=:\n\ts_waitcnt vmcnt(%0)\n.Lfat_x%=:"
-                                        ::"n"(DMA_BEFORE_RC), "n"(DMA_BEFORE_RC + 1 + (EPI == SC_EPI_SWIGLU ? 16 : 32)), "v"(relax) : "vcc", "memory");
+                // (relax = 2: the tile also issued the 4 DMA rounds of its first residual row tile behind that DMA)
+                if (X == 0) asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\ts_cbranch_vccz .Lfat_w%=\n\tv_cmp_ne_u32 vcc, 1, %3\n\ts_cbranch_vccz .Lfat_v%=\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lfat_x%=\n"
+                                        ".Lfat_v%=:\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lfat_x%=\n.Lfat_w%=:\n\ts_waitcnt vmcnt(%0)\n.Lfat_x%=:"
+                                        ::"n"(DMA_BEFORE_RC), "n"(DMA_BEFORE_RC + 1 + (EPI == SC_EPI_SWIGLU ? 16 : 32)), "n"(DMA_BEFORE_RC + 1 + 4 + (EPI == SC_EPI_SWIGLU ? 16 : 32)),
+                                        "v"(relax) : "vcc", "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_BEFORE_RC) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -690,6 +693,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     {
         const int n0b = __builtin_amdgcn_readfirstlane(tn * BN2 + wc * 128);
         lds_load16(bias ? bias + n0b : W, bias ? 256u : 0u, smem + SLAB_OFF + wave * 8192 + 4096, (unsigned)lane * 16u, 0u);
+        // ... and the first 16-row tile of the wave's residual block to its C slab (4 rounds of 4 rows x 256 B; the counted wait of the
+        // next iteration 0 knows about them, `relax` = 2): its ~2.6 us of HBM latency pass under the K loop instead of at the head of
+        // the epilogue.  Slab layout applied at the source: LDS position (row, chunk p) receives chunk p ^ row.
+        if (EPI != SC_EPI_SWIGLU && R) {
+            const int m0b = __builtin_amdgcn_readfirstlane(tm * BM2 + wr * 128);
+            const int rvb = (M - m0b) < 0 ? 0 : ((M - m0b) > 16 ? 16 : (M - m0b));
+            const unsigned rvo = (unsigned)(lane >> 4) * (unsigned)ldr * 2u + (unsigned)((((lane & 15) ^ (lane >> 4)) & 15) << 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                lds_load16(R + (size_t)m0b * (size_t)ldr + n0b, (unsigned)rvb * (unsigned)ldr * 2u, smem + SLAB_OFF + wave * 8192 + i * 1024,
+                           (rvo ^ (unsigned)(i * 64)) + (unsigned)(i * 4) * (unsigned)ldr * 2u, 0u);
+        }
     }
     FAT_STAMP(0);
     iter(std::integral_constant<int, 0>{}, std::true_type{}, 0);    // (writes every accumulator: nothing to zero)
@@ -807,6 +822,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 *reinterpret_cast<sc_u2*>(cslab + (acc_o ^ (nj * 32))) = sc_u2{pack2(v[0], v[1]), pack2(v[2], v[3])};
             }
         };
+        auto cmath_r = [&](int mi, const sc_u2 (&bq)[8], const sc_u2 (&rr)[8]) {             // cmath with a residual, bias as fp16 pairs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj) {
+                float v[4], b4[4], r4[4];
+                h4f(bq[nj], b4);
+                h4f(rr[nj], r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (EPI == SC_EPI_COLSCALE ? (acc[mi][nj][e] + b4[e]) * cscale : epi_apply(acc[mi][nj][e] + b4[e], EPI)) + r4[e];
+                if (EPI == SC_EPI_GELU_ERF) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                *reinterpret_cast<sc_u2*>(cslab + (acc_o ^ (nj * 32))) = sc_u2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        };
         auto cslab_rd = [&](sc_u4 (&d)[4]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const sc_u4*>(cslab + (row_o ^ (i * 64)) + i * 1024);
@@ -899,27 +927,33 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         } else if (R) {
             // (the bias values are made opaque on each side of this branch: hipcc otherwise hoists the `acc + bias` adds common to both
             // sides above the branch and parks the sums in AGPRs and scratch)
-            // residual rows are requested three row tiles ahead, and before the stores of the step in between (vmcnt retires in order: a
-            // load issued behind stores could only be consumed after those stores have completed)
-            float bv[8][4];
+            // residual rows are requested three row tiles ahead (row tile 0: by DMA at the top of the tile), and before the stores of the step in
+            // between (vmcnt retires in order: a load issued behind stores could only be consumed after those stores have completed)
+            // (bias kept as fp16 pairs on this side and widened per use: 16 registers less across the steps - this side spilled loaded
+            // residual rows behind vmcnt(0) otherwise; made opaque so that hipcc does not hoist the `acc + bias` adds common to both sides
+            // of the branch above it)
+            sc_u2 bq[8];
 #pragma unroll
             for (int nj = 0; nj < 8; ++nj) {
-                h4f(*reinterpret_cast<const sc_u2*>(bslot + nj * 32), bv[nj]);
-                asm volatile("" : "+v"(bv[nj][0]), "+v"(bv[nj][1]), "+v"(bv[nj][2]), "+v"(bv[nj][3]));     // see the note at the branch
+                bq[nj] = *reinterpret_cast<const sc_u2*>(bslot + nj * 32);
+                asm volatile("" : "+v"(bq[nj]));
             }
-            sc_u4 rg[3][4];
+            sc_u4 rg[2][4];
             sc_u2 rr[8];
-            load_res(0, rg[0]); load_res(1, rg[1]); load_res(2, rg[2]);
-            rslab_rw(rg[0], rr);                                  // (after the bias reads: the slab's first KiB held the bias)
+            load_res(1, rg[1]); load_res(2, rg[0]);
+            // row tile 0 came with the tile's DMA (see the top of the tile loop): its values in the accumulator layout, read before the C
+            // slab takes the first results
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj) rr[nj] = *reinterpret_cast<const sc_u2*>(cslab + (acc_o ^ (nj * 32)));
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 // (the stores are not deferred by a step here - the residual slab traffic of the next row tile covers most of the C slab's
                 // read latency, and 16 registers fewer are live across the math: this side of the branch is the tight one)
-                cmath(mi, bv, rr, true);
-                if (mi + 3 < 8) load_res(mi + 3, rg[mi % 3]);
+                cmath_r(mi, bq, rr);
                 sc_u4 d[4];
                 cslab_rd(d);
-                if (mi + 1 < 8) rslab_rw(rg[(mi + 1) % 3], rr);
+                if (mi + 1 < 8) rslab_rw(rg[(mi + 1) & 1], rr);
+                if (mi + 3 < 8) load_res(mi + 3, rg[(mi + 1) & 1]);     // (into the registers the slab write above has just read)
                 cstore(mi, d);
             }
         } else {
