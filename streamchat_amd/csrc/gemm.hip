@@ -648,7 +648,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     auto iter = [&](auto Xc, auto Fc, int k) {
         constexpr int X = decltype(Xc)::value;
         constexpr bool FIRST = decltype(Fc)::value;
-        const int fin = (k + 1 >= nk) ? 1 : 0;
+        // (nk made opaque here: for the peeled iterations `fin` is the same for every tile, hipcc computed it once in the kernel prologue,
+        // kept it in a VGPR across everything, spilled it - and reloaded it here behind a vmcnt(0) that drained the DMA pipeline once per
+        // tile in the SwiGLU and rotary kernels)
+        int nk_here = nk;
+        asm volatile("" : "+s"(nk_here));
+        const int fin = (k + 1 >= nk_here) ? 1 : 0;
         const int relax = (PERSIST && k == 0 && tcount > 0) ? (R && EPI != SC_EPI_SWIGLU ? 2 : 1) : 0;       // stores of the previous tile's epilogue may still be in flight
         // s_nop: the accumulators are zeroed by VALU writes in the loop preheader and the hazard recognizer does not know that the asm
         // below reads them as MFMA SrcC; everything after this statement is in the loop body, so three wait states are guaranteed
