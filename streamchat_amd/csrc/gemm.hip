@@ -704,11 +704,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         if (EPI != SC_EPI_SWIGLU && R) {
             const int m0b = __builtin_amdgcn_readfirstlane(tm * BM2 + wr * 128);
             const int rvb = (M - m0b) < 0 ? 0 : ((M - m0b) > 16 ? 16 : (M - m0b));
-            const unsigned rvo = (unsigned)(lane >> 4) * (unsigned)ldr * 2u + (unsigned)((((lane & 15) ^ (lane >> 4)) & 15) << 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const unsigned row = (unsigned)(i * 4 + (lane >> 4));
                 lds_load16(R + (size_t)m0b * (size_t)ldr + n0b, (unsigned)rvb * (unsigned)ldr * 2u, smem + SLAB_OFF + wave * 8192 + i * 1024,
-                           (rvo ^ (unsigned)(i * 64)) + (unsigned)(i * 4) * (unsigned)ldr * 2u, 0u);
+                           row * (unsigned)ldr * 2u + ((((unsigned)lane ^ row) & 15u) << 4), 0u);
+            }
         }
     }
     FAT_STAMP(0);
@@ -1129,7 +1130,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         if (fat < 0) { const char* e = getenv("SC_GEMM_FAT"); fat = e ? atoi(e) : 1; }
         if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31) && lda % 8 == 0 &&
             (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&          // 16-byte DMA granules
-            (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!R || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(R) & 7) == 0))) {
+            (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!R || (ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0))) {       // (16-byte residual rows: loads along rows + the DMA of the first row tile)
             // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
             // fetched under the epilogue of the current one
             const bool fp = persist && fat != 2 && nt_all > n_cu;

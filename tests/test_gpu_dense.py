@@ -417,3 +417,19 @@ def test_gemm_randomised_shape_stress():
             tol = 2e-3 + 2e-3 * ref.abs()
             bad = int((err > tol).sum())
             assert bad == 0, (case, rep, M, N, K, epi, use_bias, use_res, bad, float(err.max()))
+
+
+def test_gemm_residual_with_a_padded_leading_dimension():
+    """The residual rows of the hand-scheduled GEMM arrive by row-wise 16-byte loads and, for the first 16-row tile of every wave, by LDS
+    DMA: both address rows through `ldr`.  Residuals that are column slices of a wider buffer (ldr = N + 8 / N + 32: still 16-byte rows, row offsets with every low address bit in use; N + 4:
+    8-byte rows, dispatched to the other kernel; N + 256) must give the same result as a contiguous copy - bit for bit."""
+    M, N, K = 2500, 1024, 1024
+    a, w, b = _rand((M, K), 71), _rand((N, K), 72, K ** -0.5), _rand((N,), 73)
+    for pad in (8, 4, 32, 256):
+        wide = _rand((M, N + pad), 74 + pad)
+        r_view = wide[:, :N]
+        ref = ops.gemm(a, w, b, r_view.contiguous(), "none")
+        out = ops.gemm(a, w, b, r_view, "none")
+        assert torch.equal(out, ref), (pad, float((out.float() - ref.float()).abs().max()))
+        z = a.float() @ w.float().t() + b.float() + r_view.float()
+        torch.testing.assert_close(out.float(), z, rtol=2e-3, atol=2e-3)
