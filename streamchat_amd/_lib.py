@@ -74,6 +74,13 @@ def load():
         raise StreamChatHipError(
             f"{LIB_PATH} not found: build it with `python -m streamchat_amd.build` (hipcc, gfx950). "
             "streamchat_amd has no CPU / PyTorch fallback path.")
+    # The library's HIP calls must bind to the SAME runtime torch uses: torch ships its own libamdhip64 / libhsa-runtime64 and the .so links
+    # the system ones; whichever is in the process first provides the symbols.  Loaded before torch, the library would talk to a second
+    # runtime that finds no device once torch's has opened it ("no ROCm-capable device", seen when build() and smoke() ran in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
