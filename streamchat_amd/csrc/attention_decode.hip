@@ -1,0 +1,283 @@
+// Decode-side attention kernels of sc_attention_f16 (attention.hip holds the tile kernel, the dispatch and the C entry points):
+// the split-KV merge k_attn_combine and the per-wave streaming kernel k_attn_decode.  A translation unit of their own because
+// attention.hip is built with hipcc's iterative-ILP machine scheduler (good for the MFMA-bound tile kernel: +3 % on the 49 k prefill),
+// which costs these HBM-bound kernels 0.6-2 % (profiles/r03_run49_51_attn_sched_strategy.md): this file takes the default scheduler.
+#include "sc_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef short sc_s4 __attribute__((ext_vector_type(4)));
+
+// 16-byte LDS-DMA through a raw buffer resource (see attention.hip)
+__device__ __forceinline__ void lds_load16(const void* base, int extent, char* lds, unsigned voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// merge of the split-KV partials: out = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).  One workgroup (DH threads) per
+// (batch, head, query): the split weights are computed once by the first wave (one lane per split), then every thread owns one
+// output dimension and sums the weighted partials with independent loads.
+template <int DH>
+__global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restrict__ O, int ldo, int Sq, int Hq, int nsplit, int o_hs, long o_bs) {
+    __shared__ float wgt[1024];
+    __shared__ float inv_den;
+    const int row = blockIdx.x;                       // (b*Hq + h)*Sq + q
+    const int q = row % Sq, bh = row / Sq, h = bh % Hq, b = bh / Hq;
+    const float* pp = part + (size_t)row * nsplit * (DH + 2);
+    // NW groups of DH threads walk the partials in an interleaved order, 8 independent loads in flight each: with a single group the
+    // kernel was one dependent load chain per output element (7.9 us for 128 partials: latency, not bytes).  The first batch of every
+    // thread is requested BEFORE the split weights are computed (they only multiply it): the two load latencies overlap instead of adding.
+    constexpr int NW = 1024 / DH < 8 ? 1024 / DH : 8;
+    __shared__ float red[NW][DH];
+    const int d = threadIdx.x % DH, w = threadIdx.x / DH;
+    float v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v0[u] = (w + u * NW < nsplit) ? pp[(w + u * NW) * (DH + 2) + d] : 0.f;
+    if (threadIdx.x < 64) {
+        float M = -INFINITY;
+        for (int i = threadIdx.x; i < nsplit; i += 64) M = fmaxf(M, pp[i * (DH + 2) + DH]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) M = fmaxf(M, __shfl_xor(M, s, 64));
+        float den = 0.f;
+        for (int i = threadIdx.x; i < nsplit; i += 64) {
+            const float m = pp[i * (DH + 2) + DH];
+            const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+            wgt[i] = w;
+            den += pp[i * (DH + 2) + DH + 1] * w;
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) den += __shfl_xor(den, s, 64);
+        if (threadIdx.x == 0) inv_den = den > 0.f ? 1.0f / den : 0.f;
+    }
+    __syncthreads();
+    float num = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (w + u * NW < nsplit) num += v0[u] * wgt[w + u * NW];
+    int i = w + 8 * NW;
+    for (; i + 7 * NW < nsplit; i += 8 * NW) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(i + u * NW) * (DH + 2) + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) num += v[u] * wgt[i + u * NW];
+    }
+    for (; i < nsplit; i += NW) num += pp[i * (DH + 2) + d] * wgt[i];
+    red[w][d] = num;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int u = 1; u < NW; ++u) num += red[u][d];
+        O[(size_t)b * (size_t)o_bs + (size_t)q * (size_t)ldo + h * o_hs + d] = (_Float16)(num * inv_den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decode attention (few query rows against a long KV cache; batch-1 decode packs the G query heads of a KV group as G <= 16 query
+// rows of one "head", llm.py _decode_one / DecodeGraph): HBM-bound, 2.8 GB of K/V per token at a 49 k context.  k_attn above serves
+// this shape with one workgroup per (head, split) in which only wave 0 has queries and ONE 64-row tile is in flight behind a block
+// barrier (4.4 TB/s).  Here every WAVE is an independent stream over its own contiguous run of 32-row chunks - no block barrier in
+// the loop - and keeps about three chunks (48 KB) in flight:
+//   K: straight from global memory into MFMA A-operand registers (a 16 x 32 fragment is 16 bytes per lane; each element is used
+//      once, so staging it in LDS would only add traffic), two register sets, re-issued as soon as the S MFMAs have consumed them;
+//   V: buffer_load ... lds into a per-wave ring of three 8 KiB stages (P.V needs V transposed: ds_read_b64_tr_b16), completion by a
+//      counted s_waitcnt vmcnt - the loads of a wave retire in order;
+//   rows past the wave's range are outside the buffer resource's extent: zeros, no memory traffic (the row part of every address
+//   stays in the VGPR offset, which is what the range check covers).
+// Exact online softmax per chunk (the loop is bandwidth-bound, the VALU work is free).  The four waves of a workgroup cover four
+// consecutive quarters of one split; they merge their (O, m, l) through LDS at the end, so a workgroup leaves ONE partial per split
+// in the layout k_attn_combine reads: half as many partials as before at the same number of waves streaming.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DCH = 32;                            // kv rows per chunk
+constexpr int DEC_STAGES = 3;
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+                                                        const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
+                                                        const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one V chunk (8 KiB at Dh = 128)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit, h = bh % Hq, b = bh / Hq;
+    const int hk = h / (Hq / Hkv);
+    const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
+    // chunks of this split, then of this wave
+    const int nch = (kv_valid + DCH - 1) / DCH, cps = (nch + nsplit - 1) / nsplit;
+    const int s_lo = min(split * cps, nch), s_hi = min(s_lo + cps, nch);
+    const int cpw = (s_hi - s_lo + 3) >> 2;
+    const int c_lo = min(s_lo + wave * cpw, s_hi), c_hi = min(c_lo + cpw, s_hi);
+    const int row_end = min(c_hi * DCH, kv_valid);                                      // rows of this wave: [c_lo * 32, row_end)
+
+    // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements)
+    sc_h8 qf[DS];
+    {
+        const int qr = rl < Sq ? rl : Sq - 1;
+        const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+    }
+    const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
+    const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
+    const int k_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldv + DH) * 2u) : 0;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kbase), 0, c_lo < c_hi ? k_ext : 0, 0x00020000);
+    // per-lane offsets inside a chunk: K fragment (kvb, ds) = row kvb*16 + rl, 16 bytes at element (ds*4 + g)*8;
+    // V granule j*64 + lane = row j*4 + (lane>>4), 16-byte slot (lane&15) ^ ((row&7)<<1)   (the swizzle the transpose reads below undo)
+    unsigned k_vo[2], v_vo[8];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) k_vo[kvb] = ((unsigned)(kvb * 16 + rl) * (unsigned)ldk + (unsigned)(g * 8)) * 2u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int vr = j * 4 + (lane >> 4); v_vo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)(((lane & 15) ^ ((vr & 7) << 1)) * 8)) * 2u; }
+    char* vring = smem + wave * (DEC_STAGES * CHB);
+    const unsigned vbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (DEC_STAGES * CHB));
+    const int vrow = 4 * g + (rl >> 2);
+    int v_off[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) v_off[db] = vrow * VROW + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+
+    auto issue = [&](int c, sc_u4 (&kr)[2][DS]) {              // 2*DS register loads + 8 LDS-DMA = 16 vm ops at Dh = 128, in this order
+        const unsigned ro_k = (unsigned)c * (unsigned)(DCH * ldk * 2), ro_v = (unsigned)c * (unsigned)(DCH * ldv * 2);
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) kr[kvb][ds] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (int)(ro_k + k_vo[kvb] + ds * 64), 0, 0);
+        char* dst = vring + (c % DEC_STAGES) * CHB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_load16(vbase, c < c_hi ? v_ext : 0, dst + j * 1024, ro_v + v_vo[j], 0);
+    };
+
+    sc_f4 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto compute = [&](int c, sc_u4 (&kr)[2][DS], auto reissue) {
+        // ---- S^T = K . Q^T for the 32 rows (this consumes the K registers) ----
+        sc_f4 s[2];
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb) {
+            s[kvb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) s[kvb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, kr[kvb][ds]), qf[ds], s[kvb], 0, 0, 0);
+        }
+        // the MFMAs above have READ kr; make that visible to the scheduler before the registers are loaded again
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        reissue();
+        // ---- exact online-softmax step ----
+        const int kv0 = c * DCH + g * 4;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kvb][r] = (kv0 + kvb * 16 + r < row_end) ? s[kvb][r] : -INFINITY;
+                tmax = fmaxf(tmax, s[kvb][r]);
+            }
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto bsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1])) * scale_log2;
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] *= alpha;
+        sc_h8 pf;
+        float ps = 0.f;
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][r], scale_log2, -m_use));
+                ps += p;
+                pf[kvb * 4 + r] = (_Float16)p;
+            }
+        l_run += ps;
+        // ---- O^T += V^T . P^T : the V chunk must have landed (everything issued after it may stay in flight: 16 vm ops per chunk) ----
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DS + 8) : "memory");
+        // The transpose reads are inline asm: behind a builtin LDS read hipcc puts s_waitcnt vmcnt(0) (the LDS-DMA of later chunks "may
+        // alias" it), which would drain the whole prefetch queue on every chunk.  The stages of the ring are disjoint by construction.
+        const unsigned sa = vbase_lds + (unsigned)((c % DEC_STAGES) * CHB);
+        sc_s4 lo[DB], hi[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[db]) : "v"(sa + (unsigned)v_off[db]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[db]) : "v"(sa + (unsigned)v_off[db]), "n"(16 * VROW));
+        }
+        static_assert(DB == 8, "the lgkmcnt fence below names 16 registers");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
+                                              "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            typedef short sc_s8 __attribute__((ext_vector_type(8)));
+            const sc_s8 v8 = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi[db][0], hi[db][1], hi[db][2], hi[db][3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, v8), pf, o[db], 0, 0, 0);
+        }
+    };
+
+    // ---- the stream: chunks c_lo .. c_hi - 1; chunk c + 2 is requested right after the S MFMAs of chunk c ----
+    sc_u4 ka[2][DS], kb[2][DS];
+    if (c_lo < c_hi) {
+        issue(c_lo, ka);
+        issue(c_lo + 1, kb);                       // (past c_hi: zero extent -> no traffic)
+        for (int c = c_lo; c < c_hi; c += 2) {
+            compute(c, ka, [&] { issue(c + 2, ka); });
+            if (c + 1 < c_hi) compute(c + 1, kb, [&] { issue(c + 3, kb); });
+            else break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the ring is reused / the block ends
+    // ---- merge the four waves of the split through LDS (aliases the V rings: every wave is done with its own) ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* mo = reinterpret_cast<float*>(smem);             // [4][DH][16] O^T, then [4][16] m, [4][16] l
+    float* mm = mo + 4 * DH * 16;
+    float* ml = mm + 64;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[(wave * DH + db * 16 + g * 4 + r) * 16 + rl] = o[db][r];
+    if (g == 0) { mm[wave * 16 + rl] = m_run; ml[wave * 16 + rl] = l_run; }
+    __syncthreads();
+    for (int e = tid; e < Sq * DH; e += 256) {
+        const int q = e / DH, d = e - q * DH;
+        float M = fmaxf(fmaxf(mm[q], mm[16 + q]), fmaxf(mm[32 + q], mm[48 + q]));
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[w * 16 + q];
+            const float wt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+            acc += mo[(w * DH + d) * 16 + q] * wt;
+            l += ml[w * 16 + q] * wt;
+        }
+        float* pp = part + ((((size_t)b * Hq + h) * Sq + q) * nsplit + split) * (DH + 2);
+        pp[d] = acc;
+        if (d == 0) { pp[DH] = M; pp[DH + 1] = l; }
+    }
+}
+
+}  // namespace
+
+// launchers used by attention.hip
+void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B, int Sq, int Hq, int nsplit, int o_hs, long o_bs, hipStream_t s) {
+    const dim3 grid((unsigned)(B * Hq * Sq));
+    if (Dh == 128) hipLaunchKernelGGL((k_attn_combine<128>), grid, dim3(1024), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
+    else if (Dh == 64) hipLaunchKernelGGL((k_attn_combine<64>), grid, dim3(512), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
+    else hipLaunchKernelGGL((k_attn_combine<32>), grid, dim3(256), 0, s, part, (_Float16*)out, ldo, Sq, Hq, nsplit, o_hs, o_bs);
+}
+
+void sc_attn_decode_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
+                           const int32_t* kv_len, float* part, int nsplit, int q_hs, long q_bs, hipStream_t s) {
+    constexpr int LDS_DEC = 4 * DEC_STAGES * DCH * 128 * 2;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
+    hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)(B * Hq * nsplit)), dim3(256), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
+                       (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs);
+}
