@@ -607,8 +607,11 @@ def main():
         out["config"]["retrieval_crc32"] = zlib.crc32(sig.encode())
         if pipe.last.get("first_token") is not None:
             out["config"]["first_token"] = int(pipe.last["first_token"][0, 0])
-    if config == "C5":
-        out["config"]["rounds"] = [dict(context=r.get("context"), top_level_nodes=len(r["top"]), frames_retrieved=sum(len(x) for x in r["wanted"]))
+    if config == "C5":      # per round: what was retrieved (digest of path text + global frame ids) and what was decoded - equal for every GPU count
+        import zlib
+        out["config"]["rounds"] = [dict(context=r.get("context"), top_level_nodes=len(r["top"]), frames_retrieved=sum(len(x) for x in r["wanted"]),
+                                        retrieval_crc32=zlib.crc32(json.dumps(dict(path_text=list(r["path_text"]), wanted=r["wanted"])).encode()),
+                                        tokens_crc32=None if r.get("tokens") is None else zlib.crc32(json.dumps([int(t) for t in r["tokens"]]).encode()))
                                    for r in pipe.last["rounds"]]
     if full and a.decode_tokens > 0 and world == 1 and config != "C5":
         rate = pipe.decode_rate(a.decode_tokens)         # greedy, batch 1, after the timed region (512 tokens)

@@ -46,8 +46,11 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *               sc_decode_advance;
  *               sc_attention_f16's `causal` argument became a flag word (bit 1 = SC_ATTN_Q_PRESCALED; 0 / 1 mean what they meant)
  *      (these seven shipped in round 2 under version 2 by mistake; 3 is the first version that guarantees them)
+ *   4  round 4: the three consumers of a rotary table take the table's ROW COUNT (sc_gemm_headed_f16 `rope_tab_rows`, sc_rope_f32in_f16 and
+ *      sc_decode_qkv_tab_f16 `tab_rows`): positions known on the host (pos0 + rows) beyond the table are SC_ERR_ARG, positions read from
+ *      device memory (`positions[]`, `pos[0]`) are clamped to the last table row instead of reading past the allocation
  */
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 
 int sc_abi_version(void);
 const char* sc_last_error(void);
@@ -157,7 +160,7 @@ int sc_gemm_f16(const void* A, int lda, const void* W, const void* bias, const v
  *   mode SC_EPI_COLSCALE  (acc + bias) * col_scale for columns < lead_cols, plain beyond: the q third of CLIP's fused q|k|v projection
  *                         leaves pre-scaled for SC_ATTN_Q_PRESCALED (HF CLIPAttention scales q the same way: clip_encoder.py:76). */
 int sc_gemm_headed_f16(const void* A, int lda, const void* W, const void* bias, void* C, int ldc, int M, int N, int K,
-                       int mode, const float* rope_tab, int pos0, int lead_cols, float col_scale, sc_stream_t stream);
+                       int mode, const float* rope_tab, int rope_tab_rows, int pos0, int lead_cols, float col_scale, sc_stream_t stream);
 /* ViT token assembly + pre-LayerNorm (HF CLIPVisionEmbeddings + pre_layrnorm):
  *   out[n, 0]     = LN(cls + pos[0]);  out[n, 1 + p] = LN(patch[n*P + p] + pos[1 + p])
  * patch [N*P, D], cls [D], pos [P+1, D], out [N*(P+1), D], all fp16; D % 8 == 0, D <= 4096. */
@@ -196,13 +199,14 @@ int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, const int32_t*
  * * scale, tab[pos][1][j] = sin(..) * scale, j < Dh/2, pos < max_pos (fp32; scale = softmax scale * log2 e for the QUERY table, 1 for keys).
  * sc_rope_f32in_f16: x [rows, ldx] fp32 (projection + bias) -> out [rows, ldo] fp16: the first `heads` heads of width Dh rotated with the
  * table row positions[r] (or pos0 + r), `plain_cols` further columns cast unchanged (the V part of a k|v projection).
- * sc_decode_qkv_tab_f16: sc_decode_qkv_f16 with this arithmetic (tab_q scaled, tab_k not): q leaves pre-scaled for SC_ATTN_Q_PRESCALED. */
+ * sc_decode_qkv_tab_f16: sc_decode_qkv_f16 with this arithmetic (tab_q scaled, tab_k not): q leaves pre-scaled for SC_ATTN_Q_PRESCALED.
+ * `tab_rows` / `rope_tab_rows` (ABI 4) = positions the table holds: a position beyond it is an error where the host knows it, clamped otherwise. */
 int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, float scale, sc_stream_t stream);
-int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, const int32_t* positions, int pos0, int rows, int heads, int Dh,
+int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, int tab_rows, const int32_t* positions, int pos0, int rows, int heads, int Dh,
                       int plain_cols, void* out, int ldo, sc_stream_t stream);
 int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma,
                           float rms_eps, void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh,
-                          int K, const float* tab_q, const float* tab_k, sc_stream_t stream);
+                          int K, const float* tab_q, const float* tab_k, int tab_rows, sc_stream_t stream);
 /* Text encoders (BERT-large "mxbai-colbert" CLS embedding, reference utiles.py:704-708,725-729; MiniLM-L6 sentence
  * embedding behind HuggingFaceEmbeddings, memory_bank/memory_retrieval/local_doc_qa.py:193):
  *   sc_bert_embed_ln_f16: out[b*L + t] = LN(word[ids[b*L+t]] + pos[t] + type0)      (HF BertEmbeddings)

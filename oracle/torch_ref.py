@@ -82,6 +82,37 @@ def encode_images(sd_vit, sd_proj, pixel_values, *, heads, patch, num_layers, se
     return mm_projector(sd_proj, h[:, 1:])
 
 
+# ---- the same encode on every host core: W worker processes x `threads` intra-op threads (one fp32 forward does not scale past
+# ~32 threads; a 256-core host finishes a 440-frame stream W times sooner).  Same arithmetic per frame: a batch is `batch` frames
+# wherever it runs.  Used by the composed-parity tests at the shipped geometry and by bench.py's cpu_baseline (all-cores leg).
+def _encode_worker(rank, workers, threads, sd_vit, sd_proj, u8, out, batch, heads, patch, num_layers):
+    torch.set_num_threads(threads)
+    n = u8.shape[0]
+    nb = (n + batch - 1) // batch
+    with torch.no_grad():
+        for b in range(rank, nb, workers):
+            s, e = b * batch, min(n, (b + 1) * batch)
+            x = torch.from_numpy(preprocess_u8(u8[s:e].numpy()))
+            out[s:e] = encode_images(sd_vit, sd_proj, x, heads=heads, patch=patch, num_layers=num_layers)
+
+
+def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8, heads=16, patch=14, num_layers=24):
+    """uint8 [N,H,W,3] (numpy) -> fp32 [N, P, d_out]: preprocess_u8 + encode_images in batches of `batch`, the batches dealt round-robin to
+    `workers` spawned processes of `threads` threads each (weights, frames and the output live in shared memory)."""
+    import torch.multiprocessing as mp
+    frames = torch.from_numpy(u8).share_memory_()
+    sv = {k: v.detach().float().cpu().share_memory_() for k, v in sd_vit.items()}
+    sp = {k: v.detach().float().cpu().share_memory_() for k, v in sd_proj.items()}
+    img = u8.shape[1]
+    out = torch.empty((u8.shape[0], (img // patch) ** 2, sp["2.weight"].shape[0]), dtype=torch.float32).share_memory_()
+    workers = max(1, min(workers, (u8.shape[0] + batch - 1) // batch))
+    if workers == 1:
+        _encode_worker(0, 1, threads, sv, sp, frames, out, batch, heads, patch, num_layers)
+    else:
+        mp.spawn(_encode_worker, args=(workers, threads, sv, sp, frames, out, batch, heads, patch, num_layers), nprocs=workers, join=True)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BERT (HF BertModel; call sites reference utiles.py:707,728 and local_doc_qa.py:193 via sentence-transformers)
 # ---------------------------------------------------------------------------------------------------------
@@ -124,11 +155,12 @@ def _rms(x, w, eps):
     return w * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
 
 
-def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6, last_only=False, head_chunk=None):
+def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6, last_only=False, head_chunk=None, row_chunk=None):
     """logits [L, vocab] for inputs_embeds [L, H] (causal, positions 0..L-1): RMSNorm -> q/k/v (bias) -> rotate-half RoPE ->
     GQA causal attention -> o_proj -> +res -> RMSNorm -> down(silu(gate) * up) -> +res; final norm; lm_head.
     last_only: logits of the last position only ([vocab]); head_chunk: attention computed for that many heads at a time (same
-    arithmetic per head; bounds the [heads, L, L] score tensor for contexts of ~10 k tokens in the composed tests)."""
+    arithmetic per head; bounds the [heads, L, L] score tensor for contexts of ~10 k tokens in the composed tests); row_chunk: attention
+    for that many query rows at a time against the keys up to the chunk's last row (the 49 k-token context of the shipped geometry)."""
     L, H = embeds.shape
     x = embeds
     pos = torch.arange(L, device=x.device, dtype=torch.float32)
@@ -139,7 +171,7 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
     def rot(t):                                   # t [h, L, d]
         t1, t2 = t[..., : head_dim // 2], t[..., head_dim // 2:]
         return t * cos + torch.cat([-t2, t1], -1) * sin
-    mask = torch.full((L, L), float("-inf"), device=x.device).triu(1)
+    mask = None if row_chunk else torch.full((L, L), float("-inf"), device=x.device).triu(1)
     for i in range(layers):
         p = f"model.layers.{i}."
         h = _rms(x, sd[p + "input_layernorm.weight"], eps)
@@ -149,7 +181,14 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
         q, k = rot(q), rot(k)
         k = k.repeat_interleave(heads // kv_heads, dim=0)
         v = v.repeat_interleave(heads // kv_heads, dim=0)
-        if head_chunk:
+        if row_chunk:                                  # long contexts: query rows r0..r1 against keys 0..r1 only (the masked rest is exp(-inf) = 0)
+            a = torch.empty_like(q)
+            for r0 in range(0, L, row_chunk):
+                r1 = min(L, r0 + row_chunk)
+                s = q[:, r0:r1] @ k[:, :r1].transpose(-1, -2) / math.sqrt(head_dim)
+                s += torch.full((r1 - r0, r1), float("-inf"), device=x.device).triu(r0 + 1)
+                a[:, r0:r1] = torch.softmax(s, dim=-1) @ v[:, :r1]
+        elif head_chunk:
             a = torch.cat([torch.softmax(q[j:j + head_chunk] @ k[j:j + head_chunk].transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v[j:j + head_chunk]
                            for j in range(0, heads, head_chunk)])
         else:

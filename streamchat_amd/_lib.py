@@ -16,7 +16,7 @@ class StreamChatHipError(RuntimeError):
 
 
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
-ABI_VERSION = 3            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
+ABI_VERSION = 4            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),
@@ -44,11 +44,11 @@ SIGNATURES = {
     "sc_pool_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_avgpool_tokens_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "sc_gemm_headed_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "sc_gemm_headed_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "sc_rope_table_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
-    "sc_rope_f32in_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sc_rope_f32in_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_decode_qkv_tab_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
-                                      c_int, c_void_p, c_void_p, c_void_p]),
+                                      c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "sc_decode_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sc_rope_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "sc_rope_qk_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -73,13 +73,16 @@ def read_state_dict(path, keep=None, dtype=torch.float16):
     return out
 
 
-def load_tokenizer(path):
-    """The checkpoint's own tokenizer (builder.py:93,177: AutoTokenizer.from_pretrained(model_path, use_fast=False)); local files only.
-    `use_fast=False` is passed like upstream: it selects the slow tokenizer on the reference's pinned transformers 4.37.2; transformers
-    >= 5 (installed here) only ships the fast classes and ignores the argument."""
+def load_tokenizer(path, use_fast=None):
+    """A checkpoint directory's own tokenizer, local files only.  `use_fast=False` is what the reference passes for the LLaVA / Qwen2
+    tokenizer (builder.py:93,177: AutoTokenizer.from_pretrained(model_path, use_fast=False)): it selects the slow tokenizer on the reference's
+    pinned transformers 4.37.2 (transformers >= 5, installed here, only ships the fast classes and ignores it).  The embedding-model
+    tokenizers are loaded with the library default upstream (utiles.py:1595,1885: AutoTokenizer.from_pretrained(embedding_model_id)), so
+    `load_bert` leaves `use_fast` unset."""
     try:
         from transformers import AutoTokenizer
-        return AutoTokenizer.from_pretrained(path, use_fast=False, local_files_only=True)
+        kw = {} if use_fast is None else {"use_fast": use_fast}
+        return AutoTokenizer.from_pretrained(path, local_files_only=True, **kw)
     except Exception as e:
         raise CheckpointError(f"{path}: cannot load the tokenizer ({e})") from e
 
@@ -142,7 +145,7 @@ def load_longva(model_path, device="cuda", vision_tower_path=None, max_seq=65536
     enc = V.FrameEncoder(tower, V.MMProjector(proj, device=device, prefix="model.mm_projector."), micro_batch=micro_batch)
     lm = LM.Qwen2Model(sd, qc, device=device, max_seq=max_seq, consume=True)
     del sd
-    tok = load_tokenizer(model_path) if tokenizer else None
+    tok = load_tokenizer(model_path, use_fast=False) if tokenizer else None      # builder.py:93,177
     model = LM.LlavaQwenForCausalLM(lm, enc, eos_token_id=_eos_ids(model_path, cfg, tok))
     gc = os.path.join(model_path, "generation_config.json")      # what HF's generate falls back to for arguments the caller does not pass
     if os.path.isfile(gc):

@@ -1210,11 +1210,12 @@ int launch_headed(const void* A, int lda, const void* W, const void* bias, void*
 
 // C = headed_epilogue(A W^T + bias): the GEMM whose epilogue knows that the output columns are heads of width 128 (hand-scheduled kernel only)
 extern "C" int sc_gemm_headed_f16(const void* A, int lda, const void* W, const void* bias, void* C, int ldc, int M, int N, int K, int mode,
-                                  const float* rope_tab, int pos0, int lead_cols, float col_scale, sc_stream_t stream) {
+                                  const float* rope_tab, int rope_tab_rows, int pos0, int lead_cols, float col_scale, sc_stream_t stream) {
     SC_REQUIRE(A && W && C, "sc_gemm_headed_f16: null pointer argument");
     SC_REQUIRE(M > 0 && N > 0 && K > 0 && lead_cols >= 0 && lead_cols <= N && lead_cols % 128 == 0, "sc_gemm_headed_f16: bad sizes (lead_cols: a multiple of 128 within N)");
     SC_REQUIRE(mode == SC_EPI_ROPE || mode == SC_EPI_COLSCALE, "sc_gemm_headed_f16: mode must be SC_EPI_ROPE or SC_EPI_COLSCALE");
     SC_REQUIRE(mode != SC_EPI_ROPE || (rope_tab && pos0 >= 0 && (reinterpret_cast<uintptr_t>(rope_tab) & 15) == 0), "sc_gemm_headed_f16: SC_EPI_ROPE needs a 16-byte aligned table and pos0 >= 0");
+    SC_REQUIRE(mode != SC_EPI_ROPE || (long long)pos0 + M <= (long long)rope_tab_rows, "sc_gemm_headed_f16: positions %d..%lld exceed the rotary table (%d rows)", pos0, (long long)pos0 + M - 1, rope_tab_rows);
     // what the hand-scheduled kernel serves (the caller's other route: sc_gemm_f16 with out_f32 = 1, then sc_rope_f32in_f16 - same numbers)
     if (!(N % BN2 == 0 && K % 128 == 0 && lda >= K && lda % 8 == 0 && (size_t)lda * 512 < (1ull << 31) && ldc >= N && ldc % 8 == 0 &&
           ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0))

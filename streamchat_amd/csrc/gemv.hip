@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void k_decode_qkv(const _Float16* __restrict__
                                                     const _Float16* __restrict__ bkv, const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
                                                     float eps, _Float16* __restrict__ q_out, _Float16* __restrict__ cache, int ld,
                                                     const int* __restrict__ pos, int Hq, int Hkv, int Dh, int K, float log2_theta,
-                                                    const float* __restrict__ tab_q, const float* __restrict__ tab_k) {
+                                                    const float* __restrict__ tab_q, const float* __restrict__ tab_k, int tab_rows) {
     const int lane = threadIdx.x & 63;
     const int half = Dh >> 1;
     const int task = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);   // (head, j) over q heads, then k heads, then v heads
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512) void k_decode_qkv(const _Float16* __restrict__
     const float bias0 = (live && b0) ? (float)b0[0] : 0.f, bias1 = (live && b0) ? (float)b0[half] : 0.f;
     float tcs = 1.f, tsn = 0.f;
     if (TAB && live && kind != 2) {
-        const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)row * (size_t)Dh;
+        const int trow = row < 0 ? 0 : (row >= tab_rows ? tab_rows - 1 : row);      // the position lives in device memory: clamp to the table, never read past it
+        const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)trow * (size_t)Dh;
         tcs = t[j]; tsn = t[half + j];
     }
     // RMSNorm of x once per workgroup into LDS; the first four K-slices of both weight rows are requested before it (see k_gemv)
@@ -287,15 +288,15 @@ extern "C" int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq
     const int wpb = pick_wpb(0);
     hipLaunchKernelGGL(k_decode_qkv<false>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
-                       cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta), (const float*)nullptr, (const float*)nullptr);
+                       cache_ld, pos, q_heads, kv_heads, Dh, K, log2f(theta), (const float*)nullptr, (const float*)nullptr, 0);
     SC_CHECK_LAUNCH("sc_decode_qkv_f16");
     return SC_OK;
 }
 
 extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma, float rms_eps,
                                      void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh, int K,
-                                     const float* tab_q, const float* tab_k, sc_stream_t stream) {
-    SC_REQUIRE(Wq && Wkv && x && q_out && cache && pos && tab_q && tab_k, "sc_decode_qkv_tab_f16: null pointer argument");
+                                     const float* tab_q, const float* tab_k, int tab_rows, sc_stream_t stream) {
+    SC_REQUIRE(Wq && Wkv && x && q_out && cache && pos && tab_q && tab_k && tab_rows > 0, "sc_decode_qkv_tab_f16: null pointer argument / empty rotary table");
     SC_REQUIRE(q_heads > 0 && kv_heads > 0 && Dh > 0 && Dh % 2 == 0 && K > 0 && K % 8 == 0, "sc_decode_qkv_tab_f16: bad sizes");
     SC_REQUIRE(cache_ld >= 2 * kv_heads * Dh, "sc_decode_qkv_tab_f16: cache row stride too small for K | V");
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
@@ -304,7 +305,7 @@ extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void
     const int wpb = pick_wpb(0);
     hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
-                       cache_ld, pos, q_heads, kv_heads, Dh, K, 0.f, tab_q, tab_k);
+                       cache_ld, pos, q_heads, kv_heads, Dh, K, 0.f, tab_q, tab_k, tab_rows);
     SC_CHECK_LAUNCH("sc_decode_qkv_tab_f16");
     return SC_OK;
 }

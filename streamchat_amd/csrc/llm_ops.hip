@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rope_table(float* __restrict__ tab, int
 
 // x [rows, ldx] fp32 = projection + bias -> out [rows, ldo] fp16: the first `heads` heads of width Dh rotated with the table row of the
 // row's position (positions[r] or pos0 + r), then `plain` further columns copied with a cast (the V part of a k|v projection)
-__global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x, int ldx, const float* __restrict__ tab, const int* __restrict__ pos, int pos0,
+__global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x, int ldx, const float* __restrict__ tab, int tab_rows, const int* __restrict__ pos, int pos0,
                                                     int rows, int heads, int Dh, int plain, _Float16* __restrict__ out, int ldo) {
     const int half = Dh / 2;
     const int per_row = heads * (half / 4) + plain / 4;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x,
             continue;
         }
         const int h = rem / (half / 4), i0 = (rem - h * (half / 4)) * 4;
-        const int p = pos ? pos[r] : pos0 + r;
+        int p = pos ? pos[r] : pos0 + r;
+        p = p < 0 ? 0 : (p >= tab_rows ? tab_rows - 1 : p);           // device-side positions are clamped to the table (host-side ones are checked before the launch)
         const float* t = tab + (size_t)p * Dh;
         const sc_f4 a = *reinterpret_cast<const sc_f4*>(xr + h * Dh + i0), b = *reinterpret_cast<const sc_f4*>(xr + h * Dh + half + i0);
         const sc_f4 cs = *reinterpret_cast<const sc_f4*>(t + i0), sn = *reinterpret_cast<const sc_f4*>(t + half + i0);
@@ -248,9 +249,11 @@ extern "C" int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, f
     return SC_OK;
 }
 
-extern "C" int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, const int32_t* positions, int pos0, int rows, int heads, int Dh, int plain_cols,
+extern "C" int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, int tab_rows, const int32_t* positions, int pos0, int rows, int heads, int Dh, int plain_cols,
                                  void* out, int ldo, sc_stream_t stream) {
     SC_REQUIRE(x && tab && out, "sc_rope_f32in_f16: null pointer argument");
+    SC_REQUIRE(tab_rows > 0 && (positions || (pos0 >= 0 && (long long)pos0 + rows <= (long long)tab_rows)),
+               "sc_rope_f32in_f16: positions %d..%lld exceed the rotary table (%d rows)", pos0, (long long)pos0 + rows - 1, tab_rows);
     SC_REQUIRE(rows > 0 && heads >= 0 && Dh > 0 && Dh % 8 == 0 && plain_cols >= 0 && plain_cols % 4 == 0 && ldx >= heads * Dh + plain_cols && ldx % 4 == 0 &&
                    ldo >= heads * Dh + plain_cols && ldo % 4 == 0,
                "sc_rope_f32in_f16: bad sizes");
@@ -258,7 +261,7 @@ extern "C" int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, cons
                "sc_rope_f32in_f16: x / table must be 16-byte aligned, out 8-byte");
     const size_t total = (size_t)rows * (heads * (Dh / 8) + plain_cols / 4);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(k_rope_f32in, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, tab, positions, pos0, rows, heads, Dh, plain_cols, (_Float16*)out, ldo);
+    hipLaunchKernelGGL(k_rope_f32in, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, tab, tab_rows, positions, pos0, rows, heads, Dh, plain_cols, (_Float16*)out, ldo);
     SC_CHECK_LAUNCH("sc_rope_f32in_f16");
     return SC_OK;
 }

@@ -103,13 +103,22 @@ class Qwen2Model:
         n, Dh, dq, dkv = x.shape[0], c.head_dim, c.heads * c.head_dim, c.kv_heads * c.head_dim
         tq, tk = self.rope_tabs(pos0 + n)
         fused = (positions is None and Dh == 128 and n >= 256 and ops.gemm_headed_ok(dq, x.shape[1], x, L["wq"], L["bq"], q_out)
-                 and ops.gemm_headed_ok(2 * dkv, x.shape[1], x, L["wkv"], L["bkv"], kv_out) and q_out.stride(0) % 8 == 0 and kv_out.stride(0) % 8 == 0)
+                 and ops.gemm_headed_ok(2 * dkv, x.shape[1], x, L["wkv"], L["bkv"], kv_out))
         if fused:
             ops.gemm_headed(x, L["wq"], L["bq"], q_out, "rope", dq, tq, pos0)
             ops.gemm_headed(x, L["wkv"], L["bkv"], kv_out, "rope", dkv, tk, pos0)
-        else:
-            ops.rope_f32in(ops.gemm(x, L["wq"], L["bq"], out_f32=True), tq, c.heads, Dh, q_out, 0, pos0, positions)
-            ops.rope_f32in(ops.gemm(x, L["wkv"], L["bkv"], out_f32=True), tk, c.kv_heads, Dh, kv_out, dkv, pos0, positions)
+            return q_out, kv_out
+        # fp32 projections + k_rope_f32in (other head dims, short prompts, unaligned views): in row blocks through ONE reused fp32 scratch,
+        # so that a long prefill on a non-7B shape does not materialise [n, dq] + [n, 2 dkv] fp32 per layer (0.7 GB at 49 k x 3584)
+        RB = 4096
+        if getattr(self, "_f32_scratch", None) is None or self._f32_scratch.shape[0] < min(n, RB) or self._f32_scratch.shape[1] < max(dq, 2 * dkv):
+            self._f32_scratch = torch.empty((min(max(n, 1), RB), max(dq, 2 * dkv)), dtype=torch.float32, device=x.device)
+        for r0 in range(0, n, RB):
+            r1 = min(n, r0 + RB)
+            pz = None if positions is None else positions[r0:r1]
+            s32 = self._f32_scratch[: r1 - r0]
+            ops.rope_f32in(ops.gemm(x[r0:r1], L["wq"], L["bq"], out=s32[:, :dq], out_f32=True), tq, c.heads, Dh, q_out[r0:r1], 0, pos0 + r0, pz)
+            ops.rope_f32in(ops.gemm(x[r0:r1], L["wkv"], L["bkv"], out=s32[:, :2 * dkv], out_f32=True), tk, c.kv_heads, Dh, kv_out[r0:r1], dkv, pos0 + r0, pz)
         return q_out, kv_out
 
     def reset_cache(self, max_seq=None):
@@ -120,6 +129,7 @@ class Qwen2Model:
             self.cache = [torch.empty((self.max_seq, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=self.device)
                           for _ in range(c.layers)]
         self.cache_len = 0
+        self._nsplit_prompt = None
 
     def _buffers(self, n):
         if self._buf_rows < n:
@@ -178,6 +188,7 @@ class Qwen2Model:
             m = ops.gemm(x, L["wgu"], None, epilogue="swiglu", out=B["m"][:n])
             ops.gemm(m, L["wd"], None, residual=h2, out=h)
         self.cache_len = S
+        self._nsplit_prompt = decode_nsplit(Dh, S)          # the split-KV factor of every decode step that follows this prefill
         if tail is None:
             tail = h[n - 1:n] if last_only else h
         xn = ops.rmsnorm(tail, self.norm, c.eps)
@@ -218,8 +229,11 @@ def splice_image_embeddings(ids, embed_table, image_features, max_len=None, labe
 
 
 def decode_nsplit(head_dim: int, cache_len: int) -> int:
-    """split-KV factor of a batch-1 decode step (shared by the eager step and the captured graph, so that both sum the partials in the same
-    order).  k_attn_decode (Dh = 128): one workgroup of four streaming waves per (KV head, split), ~6 chunks of 32 rows per wave: 64 splits x
+    """split-KV factor of a batch-1 decode step.  It is fixed ONCE per prompt, from the cache length the prefill leaves (Qwen2Model.forward
+    stores it; the eager token loop keeps it for every token of that generate, a DecodeGraph built after the same prefill computes the same
+    value at construction), so the eager loop and a graph captured for that prompt sum the split partials in the same order and stay
+    bit-identical however many tokens are generated.  A graph REUSED for a later prompt of a very different length keeps the factor it was
+    captured with: same mathematics, partials merged in a different grouping (last-bit differences in the logits).  k_attn_decode (Dh = 128): one workgroup of four streaming waves per (KV head, split), ~6 chunks of 32 rows per wave: 64 splits x
     4 KV heads = one workgroup per CU at a 49 k context (measured 32 / 64 / 128 splits: 290 / 309 / 301 tok/s, profiles/r03_run5).  Other
     head dims (k_attn, one computing wave per workgroup): ~6 tiles of 64 rows per workgroup, up to 128 splits."""
     if head_dim == 128:
@@ -234,7 +248,7 @@ def _decode_one(self, embeds):
     pos0, S = self.cache_len, self.cache_len + 1
     dq, dkv, Dh, G = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim, c.heads // c.kv_heads
     h = embeds.reshape(1, -1)
-    nsplit = decode_nsplit(Dh, pos0)
+    nsplit = getattr(self, "_nsplit_prompt", None) or decode_nsplit(Dh, pos0)       # fixed by the prefill of this prompt (see decode_nsplit)
     tq, tk = self.rope_tabs(S)
     for l, L in enumerate(self.L):
         # RMSNorm fused into the projections; fp32 sums -> RoPE with the fp32 tables -> ONE rounding (q pre-scaled): the arithmetic of
@@ -442,7 +456,8 @@ class BatchDecoder:
         self.lm, self.B = lm, len(prompts)
         self.cap = max(int(e.shape[0]) for e in prompts) + max_new_tokens
         dev = lm.device
-        lm.rope_tabs(self.cap)                                   # rotary tables cover every position of this batch before a step is captured
+        self._rope_tabs = lm.rope_tabs(self.cap)                 # rotary tables cover every position of this batch before a step is captured; the
+                                                                 # reference held here keeps them alive if the process-wide cache regrows
         self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self._ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured

@@ -351,9 +351,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, epilogue: s
 LOG2E = 1.4426950408889634
 
 
-def gemm_headed_ok(N: int, K: int, *tensors) -> bool:
-    """shapes sc_gemm_headed_f16 serves (the hand-scheduled kernel): anything else takes gemm(out_f32=True) + rope_f32in / a plain scale"""
-    return N % 256 == 0 and K % 128 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+def gemm_headed_ok(N: int, K: int, a, w, bias, out) -> bool:
+    """True where sc_gemm_headed_f16 (the hand-scheduled kernel) serves the call - the SAME preconditions the C entry point checks before it
+    returns SC_ERR_UNSUPPORTED (gemm.hip): N % 256 == 0, K % 128 == 0, row strides of A and C multiples of 8 elements and >= K / N, A's row
+    stride below 2^31 / 512 bytes, 16-byte aligned A / W / C / bias.  Anything else takes gemm(out_f32=True) + rope_f32in / a plain scale."""
+    if N % 256 or K % 128:
+        return False
+    lda, ldc = (a.stride(0) if a.dim() == 2 else K), (out.stride(0) if out.dim() == 2 else N)
+    if lda < K or lda % 8 or lda * 512 >= 2 ** 31 or ldc < N or ldc % 8:
+        return False
+    return all(t is None or t.data_ptr() % 16 == 0 for t in (a, w, bias, out))
 
 
 def gemm_headed(a, w, bias, out, mode: str, lead_cols: int, rope_tab=None, pos0: int = 0, col_scale: float = 1.0):
@@ -369,7 +376,7 @@ def gemm_headed(a, w, bias, out, mode: str, lead_cols: int, rope_tab=None, pos0:
     from ctypes import c_void_p
     P = lambda t: None if t is None else c_void_p(t.data_ptr())
     with torch.cuda.device(a.device), _timed("k_gemm", 2.0 * M * N * K):
-        check(lib.sc_gemm_headed_f16(P(a), a.stride(0), P(w), P(bias), P(out), out.stride(0), M, N, K, {"rope": 4, "colscale": 5}[mode], P(rope_tab), int(pos0),
+        check(lib.sc_gemm_headed_f16(P(a), a.stride(0), P(w), P(bias), P(out), out.stride(0), M, N, K, {"rope": 4, "colscale": 5}[mode], P(rope_tab), 0 if rope_tab is None else int(rope_tab.shape[0]), int(pos0),
                                      int(lead_cols), c_float(col_scale), stream_ptr(a.device)), "sc_gemm_headed_f16")
     return out
 
@@ -402,7 +409,7 @@ def rope_f32in(x32, tab, heads: int, Dh: int, out, plain_cols: int = 0, pos0: in
     pos = None if positions is None else positions.to(device=x32.device, dtype=torch.int32).contiguous()
     from ctypes import c_void_p
     with torch.cuda.device(x32.device):
-        check(_lib.load().sc_rope_f32in_f16(c_void_p(x2.data_ptr()), x2.stride(0), c_void_p(tab.data_ptr()), ptr(pos), int(pos0), x2.shape[0], heads, Dh, plain_cols,
+        check(_lib.load().sc_rope_f32in_f16(c_void_p(x2.data_ptr()), x2.stride(0), c_void_p(tab.data_ptr()), int(tab.shape[0]), ptr(pos), int(pos0), x2.shape[0], heads, Dh, plain_cols,
                                             c_void_p(o2.data_ptr()), o2.stride(0), stream_ptr(x32.device)), "sc_rope_f32in_f16")
     return out
 
@@ -625,7 +632,8 @@ def decode_qkv_tab(wq, wkv, bq, bkv, x, rms_gamma, rms_eps: float, q_out, cache,
     with torch.cuda.device(x.device), _timed("k_gemv", 2.0 * (wq.shape[0] + wkv.shape[0]) * wq.shape[1]):
         check(lib.sc_decode_qkv_tab_f16(ptr(wq), ptr(wkv), ptr(bq), ptr(bkv), ptr(x.reshape(-1)), ptr(rms_gamma), c_float(rms_eps), c_void_p(q_out.data_ptr()),
                                         c_void_p(cache.data_ptr()), cache.stride(0), ptr(row_index), q_heads, kv_heads, Dh, wq.shape[1],
-                                        c_void_p(tab_q.data_ptr()), c_void_p(tab_k.data_ptr()), stream_ptr(x.device)), "sc_decode_qkv_tab_f16")
+                                        c_void_p(tab_q.data_ptr()), c_void_p(tab_k.data_ptr()), int(min(tab_q.shape[0], tab_k.shape[0])), stream_ptr(x.device)),
+              "sc_decode_qkv_tab_f16")
     return q_out
 
 

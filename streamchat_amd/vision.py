@@ -121,7 +121,9 @@ class CLIPVisionTower:
         # the q third of the fused q|k|v projection leaves the GEMM already multiplied by the softmax scale * log2 e (applied to the fp32
         # sum, one rounding - HF's CLIPAttention scales q the same way) where the hand-scheduled kernel serves the shape; attention then
         # runs without a per-score multiply (SC_ATTN_Q_PRESCALED)
-        pre = ops.gemm_headed_ok(3 * D, D, B["x"], B["qkv"], self.L[0]["wqkv"], self.L[0]["bqkv"]) if self.L else False
+        # (decided for ALL layers together: the attention mode must not change inside a frame batch; one unaligned layer weight sends every
+        # layer through the plain GEMM + in-kernel scale)
+        pre = bool(self.L) and all(ops.gemm_headed_ok(3 * D, D, B["x"][:M], L["wqkv"], L["bqkv"], B["qkv"][:M]) for L in self.L)
         for L in self.L:
             x = ops.layernorm(h, L["ln1"][0], L["ln1"][1], c.eps, out=B["x"][:M])
             if pre:

@@ -26,7 +26,7 @@ def test_binding_covers_header(hip_lib):
 
 
 def test_abi_version_and_error_text(hip_lib):
-    assert hip_lib.sc_abi_version() == 3
+    assert hip_lib.sc_abi_version() == 4
     # argument validation happens before any device work, so it is callable without a GPU
     rc = hip_lib.sc_kmeans_fit(None, 0, 1, 8, 1, None, None, None, 0, 1, 1e-4, None, None, None, None, None, 0, None)
     assert rc == -1
@@ -48,12 +48,16 @@ def test_headed_gemm_says_unsupported_before_any_device_work(hip_lib):
     something else: argument and shape checks run before any launch, so this is callable without a GPU (the pointers are never touched)."""
     from ctypes import c_float, c_void_p
     p = c_void_p(4096)
-    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 384, 512, 384, 1024, 4, p, 0, 128, c_float(1.0), None)       # N = 384: not a multiple of 256
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 384, 512, 384, 1024, 4, p, 4096, 0, 128, c_float(1.0), None)       # N = 384: not a multiple of 256
     assert rc == -4 and b"N % 256" in hip_lib.sc_last_error()
-    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 7, p, 0, 128, c_float(1.0), None)       # unknown mode
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 7, p, 4096, 0, 128, c_float(1.0), None)       # unknown mode
     assert rc == -1 and b"mode" in hip_lib.sc_last_error()
-    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 4, p, 0, 100, c_float(1.0), None)       # lead_cols not a head multiple
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 4, p, 4096, 0, 100, c_float(1.0), None)       # lead_cols not a head multiple
     assert rc == -1
+    rc = hip_lib.sc_gemm_headed_f16(p, 1024, p, p, p, 512, 512, 512, 1024, 4, p, 600, 100, 128, c_float(1.0), None)       # ABI 4: rows 100..611 of a 600-row rotary table
+    assert rc == -1 and b"exceed the rotary table" in hip_lib.sc_last_error()
+    rc = hip_lib.sc_rope_f32in_f16(p, 512, p, 600, None, 590, 16, 4, 128, 0, p, 512, None)                                # the same for the fp32-in rotary kernel
+    assert rc == -1 and b"exceed the rotary table" in hip_lib.sc_last_error()
     rc = hip_lib.sc_attention_f16(p, 128, p, 128, p, 128, p, 128, 1, 16, 16, 1, 1, 128, c_float(1.0), 8, None, 1, None, 0, 0, 0, 0, 0, None)   # unknown flag bit
     assert rc == -1 and b"flags" in hip_lib.sc_last_error()
 

@@ -17,8 +17,6 @@ The chunk captioner is a stand-in that names chunks by POSITION (the LLM caption
 two sides); the merge summary is derived from the captions it summarises, as upstream."""
 import os
 import sys
-import types
-import zlib
 
 import numpy as np
 import pytest
@@ -31,147 +29,14 @@ pytestmark = pytest.mark.gpu
 
 N_FRAMES = 88
 MEM = dict(chunk_size=8, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)
-QUESTION = "where did I leave the red cup and what was on the kitchen table"
 
 
-def crossfade_stream(n, seed=1234, period=16, h=336, w=336, noise=6):
-    """uint8 [n, h, w, 3]: frame i cross-fades scene floor(i / period) into the next one (+ small per-frame noise), so the stream walks a
-    continuous path through feature space and the k-means boundaries are decided by real distance comparisons.  (synthetic.frame_stream's
-    hard scene cuts are trivially separable: relative label margin 0.998 on the CPU side; this stream: 0.099 after 9 Lloyd iterations
-    that each move boundary frames - measured with oracle/torch_ref fp32 features when the test was written.)"""
-    scenes = {}
-
-    def scene(s):
-        if s not in scenes:
-            scenes[s] = np.random.default_rng([seed, 0, s]).integers(0, 256, (h, w, 3), dtype=np.uint8).astype(np.float32)
-        return scenes[s]
-    out = np.empty((n, h, w, 3), np.uint8)
-    for i in range(n):
-        s, a = divmod(i, period)
-        a = a / period
-        d = np.random.default_rng([seed, 1, i]).integers(-noise, noise + 1, (h, w, 3)).astype(np.float32)
-        out[i] = np.clip((1 - a) * scene(s) + a * scene(s + 1) + d, 0, 255).astype(np.uint8)
-    return out
-
-
-class PositionCaptioner:
-    """chunk n (in call order) -> synthetic.caption(n); a summary -> a caption derived from the prompt ids (i.e. from the captions merged)"""
-    config = types.SimpleNamespace(mm_use_im_start_end=False)
-
-    def __init__(self, device):
-        self.device, self.n = device, 0
-
-    def generate_with_image_embedding(self, ids, image_embeddings=None, **kw):
-        if image_embeddings is not None:
-            self.n += 1
-            return torch.tensor([[self.n - 1]])
-        key = torch.as_tensor(ids).reshape(-1).to("cpu", torch.int64).numpy().tobytes()
-        return torch.tensor([[1000 + zlib.crc32(key) % 1000]])
-
-
-def _describe(nodes):
-    def one(n):
-        return dict(depth=n.depth, rows=int(n.centroids.shape[0]), text=n.text, children=[one(c) for c in n.children])
-    return [one(n) for n in nodes]
-
-
-def _frame_index(t, bank0, row_elems):
-    return (t.storage_offset() - bank0.storage_offset()) // row_elems
-
-
-def _run_policy(feats, colbert, tok, record):
-    """the host policy on one feature bank (device or CPU): returns what was decided"""
-    from streamchat_amd import streaming as S, synthetic, utiles as U
-    bank = [feats[i:i + 1] for i in range(feats.shape[0])]
-    cap, stok = PositionCaptioner(feats.device), synthetic.SyntheticTokenizer()
-    torch.manual_seed(0)                                         # init_idx = CPU randperm(T)[:K] inside weighted_kmeans_feature (SURVEY 8(d))
-    import random
-    random.seed(0)
-    tree, short = S.updating_memory_buffer(bank, None, cap, stok, True, rng=np.random.RandomState(0), **MEM)
-    row = feats[0].numel()
-    short_idx = [int(_frame_index(t, feats, row)) for t in short]
-    path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, QUESTION, feats, colbert, tok, cache=U.CaptionEmbeddingCache())
-    retrieved = []
-    for t in path:                                               # a retrieved node is a run of whole frames of the bank (depth-0 chunk)
-        assert t.shape[0] == MEM["chunk_size"]
-        f0 = int(_frame_index(t, feats, row))
-        retrieved.append(list(range(f0, f0 + t.shape[0])))
-    return dict(tree=_describe(tree), short=short_idx, texts=list(texts), retrieved=retrieved, **record)
+from tests._composed import QUESTION, build, crossfade_stream, prefill_both   # noqa: E402,F401  (shared with the shipped-geometry test)
 
 
 @pytest.fixture(scope="module")
 def c2():
-    import oracle
-    from oracle import torch_ref as R
-    from streamchat_amd import ops, synthetic, text as T, utiles as U, vision as V
-    dev = torch.device("cuda:0")
-    cfg = V.CLIPVisionConfigLite(**V.VIT_L_336)
-    sd_vit = V.random_clip_state_dict(cfg, seed=0, device=dev)
-    sd_proj = V.random_projector_state_dict(1024, 3584, seed=1, device=dev)
-    enc = V.FrameEncoder(V.CLIPVisionTower(sd_vit, cfg, device=dev), V.MMProjector(sd_proj, device=dev), micro_batch=88)
-    u8 = crossfade_stream(N_FRAMES)                                                # 5.5 cross-fades of 16 frames: no trivially separable scene cuts
-    bl = T.BertConfigLite(**T.BERT_LARGE)
-    sd_bert = T.random_bert_state_dict(bl, seed=2, device=dev)
-    tok = T.HashTokenizer()
-
-    # ---- HIP path (the product functions as they are) ----
-    feats = enc.encode_frames_u8(torch.from_numpy(u8).to(dev))                     # [88, 576, 3584] fp16
-    rec_hip = {}
-    real_km = U.weighted_kmeans_feature
-
-    def km_hip(x, k, *a, **kw):
-        red, labels, info = real_km(x, k, *a, return_info=True, **kw)
-        rec_hip.update(labels=labels.cpu().numpy(), exit_iter=int(info["info"][0]), T=int(x.shape[0]))
-        return red, labels
-    U.weighted_kmeans_feature = km_hip
-    try:
-        hip = _run_policy(feats, T.BertEncoder(sd_bert, bl, device=dev), tok, rec_hip)
-    finally:
-        U.weighted_kmeans_feature = real_km
-
-    # ---- CPU path: fp32 encode (oracle/torch_ref), same policy functions, oracle providers ----
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    sv = {k: v.float().cpu() for k, v in sd_vit.items()}
-    sp = {k: v.float().cpu() for k, v in sd_proj.items()}
-    with torch.no_grad():
-        ref = torch.cat([R.encode_images(sv, sp, torch.from_numpy(R.preprocess_u8(u8[i:i + 8])), heads=16, patch=14, num_layers=24)
-                         for i in range(0, N_FRAMES, 8)]).contiguous()
-    rec_cpu = {}
-
-    def km_cpu(img_feature, K, weights=None, *, init_idx=None, reseed_idx=None, max_iter=10, **kw):
-        import random
-        Tn, P, D = img_feature.shape
-        if init_idx is None:
-            init_idx = torch.randperm(Tn)[:K]
-        if reseed_idx is None:
-            reseed_idx = [random.randint(0, Tn - 1) for _ in range(max_iter * K)]
-        X = img_feature.reshape(Tn, -1).numpy()
-        o = oracle.kmeans_fit(X, K, np.asarray(init_idx, np.int32), np.asarray(reseed_idx, np.int32), max_iter=max_iter)
-        d2 = np.sort(oracle.kmeans_dist2(X, o["centroids"]), axis=1)
-        rec_cpu.update(labels=o["labels"], exit_iter=o["iters"], T=Tn, margin=(d2[:, 1] - d2[:, 0]) / d2[:, 1])
-        return torch.from_numpy(o["centroids"]).view(K, P, D), torch.from_numpy(o["labels"])
-
-    gaps = []
-
-    def topk_cpu(q, docs, k=1, metric="cos"):
-        idx, sc = oracle.topk(q.numpy(), docs.numpy(), k, metric)
-        s = np.sort(torch.nn.functional.cosine_similarity(q[None], docs).numpy())[::-1]
-        gaps.append(float(s[0] - s[1]) if len(s) > 1 else float("inf"))
-        return torch.from_numpy(idx), torch.from_numpy(sc)
-
-    sdc = {k: v.float().cpu() for k, v in sd_bert.items()}
-
-    class RefBert:
-        def __call__(self, input_ids=None, attention_mask=None, **kw):
-            with torch.no_grad():
-                return types.SimpleNamespace(last_hidden_state=R.bert_last_hidden(sdc, input_ids.cpu(), attention_mask.cpu(), heads=16, layers=24))
-    saved = (U.weighted_kmeans_feature, ops.sim_topk)
-    U.weighted_kmeans_feature, ops.sim_topk = km_cpu, topk_cpu
-    try:
-        cpu = _run_policy(ref, RefBert(), tok, rec_cpu)
-    finally:
-        U.weighted_kmeans_feature, ops.sim_topk = saved
-    return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps, dev=dev)
+    return build(N_FRAMES, MEM, period=16, micro_batch=88)                         # 5.5 cross-fades of 16 frames: no trivially separable scene cuts
 
 
 def test_c2_short_memory_frames_identical(c2):
@@ -217,41 +82,10 @@ def test_c3_prefill_logits_and_first_token_on_the_retrieved_context(c2):
     stack at the 7B widths (2 layers, random-init: 28 / 4 heads x 128, rotary epilogue GEMMs, pre-scaled causal GQA attention, SwiGLU) -
     HIP on the fp16 HIP features vs oracle/torch_ref fp32 on the CPU path's fp32 features: last-position logits within the fp16
     tolerance and the same first token (margin between the two best logits printed)."""
-    from oracle import torch_ref as R
-    from streamchat_amd import llm as LM, streaming as S, synthetic
-    from streamchat_amd.conversation import conv_templates
-    from streamchat_amd.mm_utils import tokenizer_image_token
     from tests._tol import assert_close_fp16
-    dev = c2["dev"]
-    assert c2["hip"]["retrieved"] == c2["cpu"]["retrieved"] and c2["hip"]["short"] == c2["cpu"]["short"]
-    frames = c2["hip"]["short"] + [f for r in c2["hip"]["retrieved"] for f in r]
-    cfg = LM.Qwen2ConfigLite(**dict(LM.QWEN2_7B, layers=2, vocab=8192))
-    sd = LM.random_qwen2_state_dict(cfg, seed=4, device=dev)
-    qs = S.build_answer_prompt(QUESTION, c2["hip"]["texts"][-1], None)
-    conv = conv_templates["qwen_1_5"].copy()
-    conv.append_message(conv.roles[0], qs)
-    conv.append_message(conv.roles[1], None)
-    ids = tokenizer_image_token(conv.get_prompt(), synthetic.SyntheticTokenizer(), -200, return_tensors="pt")
-    ids = torch.where(ids >= 0, ids % cfg.vocab, ids)                       # synthetic ids into the small test vocabulary (the sentinel stays -200)
-    assert int((ids == -200).sum()) == 1
-    # ---- HIP: pieces spliced without a cat, prefill ----
-    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(sd, cfg, device=dev, max_seq=len(frames) * 576 + ids.numel() + 8))
-    pieces = [c2["feats"][f].reshape(-1, 3584) for f in frames]
-    _, _, _, _, embeds, _ = model.prepare_inputs_embeddings_for_multimodal(ids.unsqueeze(0), None, None, None, None, [pieces], ["video"])
-    assert embeds.shape[1] == len(frames) * 576 + ids.numel() - 1
-    model.lm.reset_cache()
-    logits = model.lm.forward(embeds[0]).float().cpu()
-    # ---- CPU fp32: the same prompt rows around the fp32 features of the same frames ----
-    table = sd["model.embed_tokens.weight"].float().cpu()
-    p = int((ids == -200).nonzero()[0])
-    img = torch.cat([c2["ref"][f].reshape(-1, 3584) for f in frames])
-    emb32 = torch.cat([table[ids[:p]], img, table[ids[p + 1:]]])
-    sd32 = {k: v.float().cpu() for k, v in sd.items()}
-    with torch.no_grad():
-        ref = R.qwen2_logits(sd32, emb32, heads=cfg.heads, kv_heads=cfg.kv_heads, layers=2, head_dim=cfg.head_dim, theta=cfg.rope_theta, eps=cfg.eps,
-                             last_only=True, head_chunk=4)
+    logits, ref, n_ctx = prefill_both(c2, layers=2)
     top = ref.topk(2).values
-    print(f"\n[C3] prefill of {emb32.shape[0]} tokens (2 Qwen2-7B-width layers): first token HIP {int(logits.argmax())} / CPU {int(ref.argmax())}; "
+    print(f"\n[C3] prefill of {n_ctx} tokens (2 Qwen2-7B-width layers): first token HIP {int(logits.argmax())} / CPU {int(ref.argmax())}; "
           f"best-minus-second logit {float(top[0] - top[1]):.3e} of max |logit| {float(ref.abs().max()):.3f}")
     assert_close_fp16(logits, ref, max_rel=6e-3, what="C3 last-position logits (12 k-token context)")
     assert int(logits.argmax()) == int(ref.argmax())

@@ -52,8 +52,12 @@ def test_gemm_rotary_epilogue_equals_fp32_projection_plus_rope_kernel_bitwise(M,
     ragged last row tile, a position offset (chunked prefill) and far positions"""
     a, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
     tab = ops.rope_table(pos0 + M, 128, 1e6, 0.1275 if lead == N else 1.0, "cuda:0")
-    assert ops.gemm_headed_ok(N, K, a, w, b)
-    fused = ops.gemm_headed(a, w, b, torch.empty((M, N), dtype=torch.float16, device="cuda"), "rope", lead, tab, pos0)
+    out = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    assert ops.gemm_headed_ok(N, K, a, w, b, out)
+    # (ADVICE r03: the predicate mirrors the C preconditions - an odd row stride or a misaligned view must say False, not raise later)
+    assert not ops.gemm_headed_ok(N, K, a, w, b, torch.empty((M, N + 4), dtype=torch.float16, device="cuda")[:, :N])
+    assert not ops.gemm_headed_ok(N, K, a, w, b[1:] if False else torch.empty(N + 8, dtype=torch.float16, device="cuda")[1:N + 1], out)
+    fused = ops.gemm_headed(a, w, b, out, "rope", lead, tab, pos0)
     acc = ops.gemm(a, w, b, out_f32=True)
     two = ops.rope_f32in(acc, tab, lead // 128, 128, torch.empty((M, N), dtype=torch.float16, device="cuda"), N - lead, pos0)
     assert torch.equal(fused, two)

@@ -1,6 +1,6 @@
 """GPU: the sharded (N > 1) code path of bench.py run at world size 1 (`--force-sharded`) must equal the single-GPU step through the
 reference-seam functions on the same stream — same tree, same retrieved frames, bit-identical [short | long] feature block
-(VERDICT r01 item 1).  The multi-rank control flow itself is covered on CPU by tests/test_sharded_gloo.py (gloo, world 2 and 4)."""
+(VERDICT r01 item 1).  The multi-rank control flow itself is covered on CPU by tests/test_sharded_gloo.py (gloo, world 2, 3, 4 and 8); the full-size C4 / C5 jobs run here as 8 processes on the one GPU."""
 import os
 import sys
 
@@ -153,7 +153,7 @@ def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
         dist.destroy_process_group()
 
 
-def _bench_json(args, env, nproc=1, launcher="torchrun"):
+def _bench_json(args, env, nproc=1, launcher="torchrun", timeout=900):
     """bench.py as a subprocess: under torch.distributed.run like the driver launches N > 1 (launcher="torchrun"), or as the bare command
     `python bench.py --gpus N ...` (launcher="bare": bench.py must start its ranks itself)."""
     import json
@@ -163,7 +163,7 @@ def _bench_json(args, env, nproc=1, launcher="torchrun"):
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29533"]
     cmd += [os.path.join(ROOT, "bench.py")] + args
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run(cmd, env={**base, **env}, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env={**base, **env}, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads(lines[0])
@@ -198,6 +198,51 @@ def test_processes_retrieve_and_prefill_like_one(nproc, launcher):
     assert many["encode_frames_per_s"] > 0 and many["encode_frames_per_s_1gpu_same_job"] > 0 and "SERIAL on rank 0" in many["scaling_note"]
     keys = list(many)
     assert keys.index("encode_frames_per_s") < keys.index("config")       # the encode rate leads the record
+
+
+def _full_size_pair(cfg_args, tag):
+    """the SAME full-size job as ONE process and as EIGHT processes (bare command: bench.py starts its ranks; all on device 0, gloo with host
+    staging); both JSON lines are left under gpurun_out/ when that directory exists (copied to profiles/ by hand)"""
+    import json
+    one = _bench_json(cfg_args + ["--force-sharded"], {}, timeout=1100)
+    eight = _bench_json(cfg_args + ["--gpus", "8"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=8, launcher="bare", timeout=1100)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"r04_{tag}_1proc_vs_8proc_one_gpu.jsonl"), "w") as f:
+            f.write(json.dumps(one) + "\n" + json.dumps(eight) + "\n")
+    assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["config"]["launcher"] == "self (bare command)"
+    return one, eight
+
+
+@pytest.mark.timeout(1500)
+def test_c4_full_size_4096_frames_in_8_processes_equals_one_process():
+    """BASELINE.json configs[3] AT ITS SIZE: ONE 4096-frame stream = 103 chunks dealt to EIGHT ranks by whole chunks
+    (12-13 chunks = 480-520 frames each), rank-local encode + captions, the single-stream tree policy (ten merges' worth of depth-0 nodes,
+    ONE merge k-means T = 400 on the rank owning the group), Ref broadcast, all-gather of the selected rows, 49 k-token 7B prefill on rank 0.
+    Eight processes share this box's one GPU; the collectives are gloo with host staging (RCCL refuses two ranks per device, so RCCL's own
+    transport stays unmeasured).  Retrieved frames + path text, context length and the first generated token equal the 1-process run."""
+    args = ["--config", "C4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
+    one, eight = _full_size_pair(args, "c4_4096")
+    assert eight["config"]["frames_total"] == 4096 and "4096-frame" in eight["metric"]
+    for k in ("retrieval_crc32", "first_token", "context_tokens"):
+        assert one["config"][k] == eight["config"][k], (k, one["config"][k], eight["config"][k])
+    assert eight["config"]["frames_rank0"] in (480, 520)
+
+
+@pytest.mark.timeout(2400)
+def test_c5_full_size_8192_frames_8_rounds_in_8_processes_equals_one_process():
+    """BASELINE.json configs[4] AT ITS SIZE: ONE 8192-frame ego stream in 8 question rounds of 1024 new frames, every round sharded over
+    EIGHT ranks (3-4 chunks each), the ONE persistent short / long memory tree grown over the rounds (a merge per round, deeper merges as
+    depth-1 nodes accumulate), BERT-large-CLS tree search + MiniLM dialogue memory, 7B prefill of a context that grows with the tree and a
+    64-token graph decode on rank 0 in EVERY round.  Per round: retrieved frames + path text, context length and the 64 decoded tokens
+    equal the 1-process session."""
+    args = ["--config", "C5", "--rounds", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one, eight = _full_size_pair(args, "c5_8192")
+    assert eight["config"]["frames_total"] == 8192 and len(eight["config"]["rounds"]) == 8
+    for r, (a, b) in enumerate(zip(one["config"]["rounds"], eight["config"]["rounds"])):
+        assert a == b, (r, a, b)
+        assert a["tokens_crc32"] is not None and a["context"] > 5 * 576 + 2 * 23040
+    assert one["config"]["retrieval_crc32"] == eight["config"]["retrieval_crc32"] and one["config"]["first_token"] == eight["config"]["first_token"]
 
 
 def test_weak_scaling_record_names_the_total_frames():

@@ -1,4 +1,4 @@
-"""CPU, gloo, world size 2 and 4: the WHOLE sharded memory-update / retrieval control flow (streamchat_amd/sharded.py) against
+"""CPU, gloo, world size 2, 3, 4 and 8: the WHOLE sharded memory-update / retrieval control flow (streamchat_amd/sharded.py) against
 the single-stream functions (`streaming.updating_memory_buffer` + `utiles.fast_search_tree_multi_modal_with_embedding`) on the
 same global stream: tree shape and texts, merge centroids, short-memory frames, retrieved ("wanted") frames and the fetched
 feature rows must not depend on the number of ranks (reference policy utiles.py:525-536,567-620,
@@ -210,6 +210,22 @@ def test_sharded_equals_single_stream_world2_and_world4():
     w2 = _run_world(2)
     w4 = _run_world(4)
     assert w2 == w4                                          # identical retrieved (segment, frame) indices for P = 2 and P = 4
+
+
+@pytest.mark.timeout(900)
+def test_sharded_equals_single_stream_world8():
+    """World 8 - the size BASELINE.json's C4 / C5 are defined at.  Chunk 4 over 8 ranks: the 3-frame segment is ONE chunk
+    (seven ranks own nothing of it), the 26-frame segment is 7 chunks (one rank idle, every other rank ONE chunk), so each merge group of
+    `interval` = 3 sibling chunks straddles three ranks and the merged node's rows travel point to point from two of them; the 13- and
+    9-frame segments leave four / five ranks without frames.  Same assertions as at world 2 / 4 (tree, texts, merge centroids, short and
+    retrieved rows equal the single-stream functions on every update; host RNG streams in lockstep), and the retrieved (segment, frame)
+    indices equal the world-4 run's."""
+    from streamchat_amd import dist as D
+    assert [b - a for a, b in D.partition_chunks(3, MEM["chunk_size"], 8)].count(0) == 7
+    assert [b - a for a, b in D.partition_chunks(26, MEM["chunk_size"], 8)].count(0) == 1
+    w8 = _run_world(8)
+    w4 = _run_world(4)
+    assert w8 == w4
 
 
 @pytest.mark.timeout(600)
