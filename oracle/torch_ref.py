@@ -175,6 +175,21 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
     for i in range(layers):
         p = f"model.layers.{i}."
         h = _rms(x, sd[p + "input_layernorm.weight"], eps)
+        if last_only and row_chunk and i == layers - 1:
+            # long contexts, last-position logits only: in the LAST layer every row still gives its K / V, but the query, the attention row,
+            # the output projection and the MLP are needed for the final row alone (same numbers for that row; half the attention work)
+            k = rot(F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1))
+            v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
+            q1 = F.linear(h[-1:], sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(1, heads, head_dim).transpose(0, 1)
+            t1, t2 = q1[..., : head_dim // 2], q1[..., head_dim // 2:]
+            q1 = q1 * cos[-1:] + torch.cat([-t2, t1], -1) * sin[-1:]
+            k = k.repeat_interleave(heads // kv_heads, dim=0)
+            v = v.repeat_interleave(heads // kv_heads, dim=0)
+            a = torch.softmax(q1 @ k.transpose(-1, -2) / math.sqrt(head_dim), dim=-1) @ v           # [heads, 1, d]: the last row sees every key
+            x = x[-1:] + F.linear(a.transpose(0, 1).reshape(1, heads * head_dim), sd[p + "self_attn.o_proj.weight"])
+            h = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
+            x = x + F.linear(F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"]), sd[p + "mlp.down_proj.weight"])
+            break
         q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(L, heads, head_dim).transpose(0, 1)
         k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
         v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)

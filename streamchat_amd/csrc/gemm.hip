@@ -528,13 +528,9 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 // with the accumulator tied in place, asm fragment reads, explicit waits, DMA rounds spread one per 7 MFMAs); what that bought, what
 // it needed (whole 128-byte lines per DMA pair, no bursts) and the hazards it runs into are written up in DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------------------------
-#ifdef FAT_TRACE
-// diagnostic build only (tools/trace_fat.py): per workgroup and tile the 100 MHz timestamps of tile start / end of the K loop / end of the epilogue
-#define FAT_TRACE_TILES 96
-__device__ unsigned long long g_fat_trace[256 * FAT_TRACE_TILES * 3];
-extern "C" int sc_fat_trace_read(void* dst, size_t bytes) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fat_trace), bytes) == hipSuccess ? 0 : 1; }
-#define FAT_STAMP(slot) do { if (tid == 0 && tcount < FAT_TRACE_TILES && blockIdx.x < 256) g_fat_trace[(blockIdx.x * FAT_TRACE_TILES + tcount) * 3 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
+// (the per-tile phase trace of tools/trace_fat.py hooks in at three points of the tile loop; the product build defines the hook as nothing - the
+// diagnostic build force-includes tools/diag/fat_trace.h, which holds the trace buffer, the stamp and the read-back entry point)
+#ifndef FAT_STAMP
 #define FAT_STAMP(slot)
 #endif
 template <int EPI, bool PERSIST>
@@ -636,13 +632,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
     //   t = 0..15   + the 16 fragment reads of K half 1                      | t = RB: all reads of buffer X are done -> barrier
     //   t = RB..    + the 16 DMA rounds of iteration k + 2 into buffer X     | t = RC: iteration k + 1 has landed -> wait + barrier
     //   t = RC..    + the 16 fragment reads of (k + 1, K half 0) from the other buffer (a0/b0 are free after t = 63)
-#ifndef FAT_RB
-#define FAT_RB 20
-#define FAT_RC 100
-#define FAT_DS 7
-#define FAT_RS 1
-#endif
-    constexpr int RB = FAT_RB, RC = FAT_RC, DS = FAT_DS, RS = FAT_RS;      // DS: MFMAs per DMA round, RS: MFMAs per fragment read
+    constexpr int RB = 20, RC = 100, DS = 7, RS = 1;                     // DS: MFMAs per DMA round, RS: MFMAs per fragment read (swept in round 1: profiles/r01_run143)
     constexpr int DMA_BEFORE_RC = (RC - RB + DS - 1) / DS < 16 ? (RC - RB + DS - 1) / DS : 16;
     static_assert(RB + 15 * DS < 128 && RC + 15 * RS < 128 && 15 * RS < RB, "schedule does not fit the iteration");
     auto iter = [&](auto Xc, auto Fc, int k) {
@@ -851,20 +841,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 // gfx950: a VALU write to the data registers of a 16-byte buffer store in the very next instruction corrupts the stored
                 // value (profiles/r01_run161) and hipcc does not guard it: the asm keeps the four registers allocated past the store
                 unsigned w0 = d[i][0], w1 = d[i][1], w2 = d[i][2], w3 = d[i][3];
-#if !(defined(FAT_EPI_ABL) && (FAT_EPI_ABL & 1))
                 __builtin_amdgcn_raw_buffer_store_b128(sc_u4{w0, w1, w2, w3}, rs_c, st_vo + mi * rstep_c + i * rstep4_c, 0, 0);
-#endif
                 asm volatile("s_nop 1" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
             }
         };
         auto load_res = [&](int mi, sc_u4 (&rg)[4]) {            // residual rows of row tile mi, row-major (4 rows x 256 B per instruction)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-#if defined(FAT_EPI_ABL) && (FAT_EPI_ABL & 2)
-                rg[i] = sc_u4{(unsigned)mi, (unsigned)i, 0u, 0u};
-#else
                 rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ld_vo + mi * rstep_r + i * rstep4_r, 0, 0);
-#endif
         };
         auto rslab_rw = [&](const sc_u4 (&rg)[4], sc_u2 (&rr)[8]) {  // -> this lane's residual values in the accumulator layout
 #pragma unroll

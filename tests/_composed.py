@@ -102,6 +102,8 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
     sd_bert = T.random_bert_state_dict(bl, seed=2, device=dev)
     tok = T.HashTokenizer()
 
+    import time
+    t_start = time.time()
     # ---- HIP path (the product functions as they are) ----
     feats = enc.encode_frames_u8(torch.from_numpy(u8).to(dev))                     # [n, 576, 3584] fp16
     rec_hip = {}
@@ -117,11 +119,13 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
     finally:
         U.weighted_kmeans_feature = real_km
 
+    t_hip = time.time()
     # ---- CPU path: fp32 encode (oracle/torch_ref), same policy functions, oracle providers ----
     cores = os.cpu_count() or 1
     threads = min(32, cores)
     torch.set_num_threads(threads)
     ref = R.encode_frames_u8_parallel(sd_vit, sd_proj, u8, workers=min(cpu_workers, max(1, cores // threads)), threads=threads, batch=cpu_batch)
+    t_enc = time.time()
     rec_cpu = {}
 
     def km_cpu(img_feature, K, weights=None, *, init_idx=None, reseed_idx=None, max_iter=10, **kw):
@@ -157,6 +161,8 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
         cpu = run_policy(ref, RefBert(), tok, rec_cpu, mem)
     finally:
         U.weighted_kmeans_feature, ops.sim_topk = saved
+    print(f"\n[composed] {n_frames} frames: HIP side {t_hip - t_start:.1f} s, fp32 host encode {t_enc - t_hip:.1f} s ({min(cpu_workers, max(1, cores // threads))} workers x "
+          f"{threads} threads), host policy with oracle providers {time.time() - t_enc:.1f} s")
     return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps, dev=dev)
 
 
@@ -193,6 +199,8 @@ def prefill_both(c2, layers=2, vocab=8192, row_chunk=None):
     img = torch.cat([c2["ref"][f].reshape(-1, 3584) for f in frames])
     emb32 = torch.cat([table[ids[:p]], img, table[ids[p + 1:]]])
     sd32 = {k: v.float().cpu() for k, v in sd.items()}
+    if row_chunk:
+        torch.set_num_threads(min(64, os.cpu_count() or 1))
     with torch.no_grad():
         ref = R.qwen2_logits(sd32, emb32, heads=cfg.heads, kv_heads=cfg.kv_heads, layers=layers, head_dim=cfg.head_dim, theta=cfg.rope_theta, eps=cfg.eps,
                              last_only=True, head_chunk=None if row_chunk else 4, row_chunk=row_chunk)

@@ -242,7 +242,7 @@ def test_c5_full_size_8192_frames_8_rounds_in_8_processes_equals_one_process():
     for r, (a, b) in enumerate(zip(one["config"]["rounds"], eight["config"]["rounds"])):
         assert a == b, (r, a, b)
         assert a["tokens_crc32"] is not None and a["context"] > 5 * 576 + 2 * 23040
-    assert one["config"]["retrieval_crc32"] == eight["config"]["retrieval_crc32"] and one["config"]["first_token"] == eight["config"]["first_token"]
+    assert one["config"]["context_tokens"] == eight["config"]["context_tokens"] > 200000          # the last round's context: ~210 k tokens
 
 
 def test_weak_scaling_record_names_the_total_frames():

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-tile phase timing of k_gemm_fat (diagnostic build: gemm.hip compiled with -DFAT_TRACE, linked as tools/bin/lib_trace.so, loaded
-through SC_LIB).  Each workgroup stamps the 100 MHz counter at tile start / end of the K loop / end of the epilogue; this prints, per
+"""Per-tile phase timing of k_gemm_fat.  Diagnostic build (the product library has no trace code: gemm.hip only carries three empty
+FAT_STAMP hooks): `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -include tools/diag/fat_trace.h -c streamchat_amd/csrc/gemm.hip -o
+tools/bin/gemm_trace.o`, linked with the other objects as tools/bin/lib_trace.so, loaded through SC_LIB.  Each workgroup stamps the 100 MHz counter at tile start / end of the K loop / end of the epilogue; this prints, per
 shape, the K-loop and epilogue durations and how far the workgroups' epilogues are apart in time (all CUs storing their 128 KB C tiles
 in the same few microseconds is a burst the write path has to absorb).
 
