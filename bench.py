@@ -321,13 +321,15 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
                 break
         threads = min(sweep, key=sweep.get)
         torch.set_num_threads(threads)
-        # ALL host cores: one fp32 forward stops scaling at `threads` threads, so the slice is dealt in batches of 8 frames to
-        # W = cores // threads worker processes of `threads` threads each (oracle/torch_ref.encode_frames_u8_parallel: same arithmetic per frame;
-        # weights, frames and the output in shared memory; the spawn + torch import of the workers is inside the timed region)
-        workers = max(1, min(cores // threads, (n_cpu_frames + 7) // 8))
+        # ALL host cores: one fp32 forward stops scaling at `threads` threads, so the slice is dealt in batches of 4 frames to up to
+        # 16 worker processes of 16 threads each (oracle/torch_ref.parallel_plan / encode_frames_u8_parallel: same arithmetic per frame; weights, frames
+        # and the output in shared memory; the spawn + torch import of the workers is inside the timed region).  The pool's hosts show 256 cores but
+        # run the container under a cgroup CPU quota (reported as `cpu_quota_cores`): the workers cannot burn more than that, whatever they are given.
+        workers, wthreads = R.parallel_plan(n_cpu_frames, batch=4)
         t0 = time.time()
-        feats = R.encode_frames_u8_parallel(sd, sp, u8, workers=workers, threads=threads, batch=8)      # the 64-frame slice = C1's encode
+        feats = R.encode_frames_u8_parallel(sd, sp, u8, workers=workers, threads=wthreads, batch=4)      # the 64-frame slice = C1's encode
         t_enc = time.time() - t0
+        quota = R.host_cpu_budget()[1]
     t_frame = t_enc / n_cpu_frames
     # ---- C1 in full: k-means(k=8) over the 64 encoded frames with the reference's broadcast formula, to its own exit ----
     Xs = feats.reshape(n_cpu_frames, -1)
@@ -385,11 +387,12 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     host_s = time.time() - t_all
     sys.stderr.write(f"[cpu_baseline] {host_s:.1f} s of host work\n")
     total = n_frames * t_frame + km + t_prefill
-    return dict(value=round(n_frames / total, 5), unit="frames/s", cores=threads * workers, cores_present=cores, kind="port", c1_frames_per_s=round(c1, 4),
-                thread_sweep_s_per_frame=sweep, encode_workers=workers, threads_per_worker=threads, host_seconds=round(host_s, 1),
-                sample=f"oracle/torch_ref ViT-L+projector fp32 on a {n_cpu_frames}-frame slice: {workers} worker processes x {threads} threads = {threads * workers} of the "
-                       f"{cores} cores present, batches of 8 ({t_frame:.3f} s/frame for the whole host incl. worker start-up; {threads} threads = best of the "
-                       f"single-process sweep {sweep} on a 4-frame batch) x{n_frames}; k-means and prefill legs: one process, {threads} threads; C1 RUN IN FULL: those {n_cpu_frames} frames + "
+    return dict(value=round(n_frames / total, 5), unit="frames/s", cores=min(wthreads * workers, cores), cores_present=cores, cpu_quota_cores=quota, kind="port",
+                c1_frames_per_s=round(c1, 4), thread_sweep_s_per_frame=sweep, encode_workers=workers, threads_per_worker=wthreads, host_seconds=round(host_s, 1),
+                sample=f"oracle/torch_ref ViT-L+projector fp32 on a {n_cpu_frames}-frame slice: {workers} worker processes x {wthreads} threads on the {cores} cores present "
+                       f"(cgroup CPU quota of the container: {quota} cores), batches of 4 ({t_frame:.3f} s/frame for the whole host incl. worker start-up; one process: "
+                       f"{min(sweep.values()):.3f} s/frame at {threads} threads = best of the sweep {sweep} on a 4-frame batch) x{n_frames}; k-means and prefill legs: one process, "
+                       f"{threads} threads; C1 RUN IN FULL: those {n_cpu_frames} frames + "
                        f"reference-formula k-means K=8 on their features to its exit ({it8 + 1} iterations, {t_km_c1:.1f} s) = {c1:.3f} frames/s; merge k-means: "
                        f"{km_note} x {km_iters_gpu} Lloyd passes (the GPU run's count)" + note + "; retrieval negligible")
 

@@ -96,6 +96,36 @@ def _encode_worker(rank, workers, threads, sd_vit, sd_proj, u8, out, batch, head
             out[s:e] = encode_images(sd_vit, sd_proj, x, heads=heads, patch=patch, num_layers=num_layers)
 
 
+def host_cpu_budget():
+    """(cores present, cores this process may actually burn): the second number is the cgroup CPU quota where one is set (the GPU boxes of the pool show
+    256 cores and `cpu.max = 1600000 100000`, i.e. 16 cores' worth of CPU time), else the scheduling affinity."""
+    import os
+    present, usable = os.cpu_count() or 1, len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            usable = min(usable, max(1, int(q) // int(per)))
+    except Exception:
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                usable = min(usable, max(1, q // per))
+        except Exception:
+            pass
+    return present, usable
+
+
+def parallel_plan(n_frames, batch=4):
+    """(workers, threads per worker) for encode_frames_u8_parallel on this host.  Measured on the pool's 256-core hosts (tools/probe_host.py,
+    profiles/r04_run4_host_probe.md): ONE fp32 forward is fastest at 32 threads (0.63 s/frame; 64 threads: 1.06), many small workers are much better -
+    8 x 16 threads 0.29 s/frame, 16 x 16 threads 0.15 s/frame incl. worker start-up - so: 16 threads per worker, up to 16 workers."""
+    import os
+    cores = os.cpu_count() or 1
+    if cores < 32:
+        return 1, cores
+    return max(1, min(16, cores // 16, (n_frames + batch - 1) // batch)), 16
+
+
 def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8, heads=16, patch=14, num_layers=24):
     """uint8 [N,H,W,3] (numpy) -> fp32 [N, P, d_out]: preprocess_u8 + encode_images in batches of `batch`, the batches dealt round-robin to
     `workers` spawned processes of `threads` threads each (weights, frames and the output live in shared memory)."""

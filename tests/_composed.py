@@ -122,9 +122,9 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
     t_hip = time.time()
     # ---- CPU path: fp32 encode (oracle/torch_ref), same policy functions, oracle providers ----
     cores = os.cpu_count() or 1
-    threads = min(32, cores)
-    torch.set_num_threads(threads)
-    ref = R.encode_frames_u8_parallel(sd_vit, sd_proj, u8, workers=min(cpu_workers, max(1, cores // threads)), threads=threads, batch=cpu_batch)
+    workers, threads = (1, min(32, cores)) if cpu_workers <= 1 else R.parallel_plan(n_frames, batch=cpu_batch)
+    torch.set_num_threads(min(32, cores))
+    ref = R.encode_frames_u8_parallel(sd_vit, sd_proj, u8, workers=workers, threads=threads, batch=cpu_batch)
     t_enc = time.time()
     rec_cpu = {}
 
@@ -161,7 +161,7 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
         cpu = run_policy(ref, RefBert(), tok, rec_cpu, mem)
     finally:
         U.weighted_kmeans_feature, ops.sim_topk = saved
-    print(f"\n[composed] {n_frames} frames: HIP side {t_hip - t_start:.1f} s, fp32 host encode {t_enc - t_hip:.1f} s ({min(cpu_workers, max(1, cores // threads))} workers x "
+    print(f"\n[composed] {n_frames} frames: HIP side {t_hip - t_start:.1f} s, fp32 host encode {t_enc - t_hip:.1f} s ({workers} workers x "
           f"{threads} threads), host policy with oracle providers {time.time() - t_enc:.1f} s")
     return dict(hip=hip, cpu=cpu, feats=feats, ref=ref, gaps=gaps, dev=dev)
 

@@ -26,7 +26,7 @@ from tests._composed import build, prefill_both   # noqa: E402
 
 @pytest.fixture(scope="module")
 def c2():
-    return build(N_FRAMES, MEM, period=PERIOD, micro_batch=440, cpu_workers=8)
+    return build(N_FRAMES, MEM, period=PERIOD, micro_batch=440, cpu_workers=16, cpu_batch=4)
 
 
 def test_shipped_short_memory_frames_identical(c2):
