@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU-baseline slice (SURVEY 8(d): 64 = C1's encode)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
-    ap.add_argument("--with-captions", type=int, nargs="?", const=2, default=0, metavar="STEPS",
-                    help="AFTER the headline measurement: STEPS more steps (default 2) in which the chunk captioner is the HIP 7B model itself "
+    ap.add_argument("--with-captions", type=int, nargs="?", const=2, default=1, metavar="STEPS",
+                    help="AFTER the headline measurement: STEPS more steps (default 1; 0 = off) in which the chunk captioner is the HIP 7B model itself "
                          "(one 23 k-token prefill + 128 new tokens per 40-frame chunk through llm.BatchDecoder, reference utiles.py:539-559), "
                          "reported as a separate `product` object; `value` is untouched (the metric names encode+select+retrieve+prefill)")
     return ap.parse_args()
@@ -96,6 +96,29 @@ class TimedCaptioner:
         r["prefill_flop"] += sum(2 * k * 6.53e9 + 2 * k * k * 3584 * 28 for k in n)                      # SURVEY 8(d) flop model (causal)
         r["decode_bytes"] += steps * (14.1e9 + sum(2 * 28 * 4 * 128 * (k + steps / 2) * 2 for k in n))     # per step: weights once + every sequence's K/V
         return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
+
+
+def measure_product(pipe, k, n_total):
+    """`k` steps of the C3 step with the HIP 7B model as chunk captioner + merge summariser (TimedCaptioner), after one warm-up step"""
+    pipe.captioner = TimedCaptioner(pipe.model)
+    pipe.step()                                                  # warm-up: BatchDecoder's cache allocation, graph capture
+    pipe.captioner = cp = TimedCaptioner(pipe.model)
+    torch.cuda.synchronize(); t0c = time.perf_counter()
+    for _ in range(k):
+        pipe.step()
+    torch.cuda.synchronize(); dtc = time.perf_counter() - t0c
+    r = cp.rec
+    return dict(
+        product_frames_per_s=round(n_total * k / dtc, 2), ms_per_step=round(dtc / k * 1e3, 1), steps=k,
+        what="the C3 step with the HIP LongVA-7B-shape model as chunk captioner + merge summariser (reference utiles.py:539-559,591-607; "
+             "batched: llm.BatchDecoder, temperature 0.1, 128 new tokens): encode + caption + select + retrieve + answer prefill",
+        chunks_per_step=r["chunks"] // k, prompt_tokens_per_chunk=r["prompt_tokens"] // max(r["chunks"], 1),
+        caption_prefill_s_per_step=round(r["prefill_s"] / k, 3), caption_decode_s_per_step=round(r["decode_s"] / k, 3), summary_s_per_step=round(r["summary_s"] / k, 3),
+        caption_prefill=dict(bound="mfma", achieved=round(r["prefill_flop"] / max(r["prefill_s"], 1e-9) / 1e12, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
+                             frac=round(r["prefill_flop"] / max(r["prefill_s"], 1e-9) / 1e12 / MFMA_PEAK_TF, 4)),
+        caption_decode=dict(bound="hbm", achieved=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
+                            tokens_per_s_aggregate=round(r["new_tokens"] / max(r["decode_s"], 1e-9), 1), ms_per_decode_step=round(r["decode_s"] / max(r["decode_steps"], 1) * 1e3, 2)))
 
 
 class Pipeline:
@@ -310,9 +333,9 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     enc = lambda xs: torch.cat([R.encode_images(sd, sp, xs[i:i + 16], heads=16, patch=14, num_layers=24) for i in range(0, xs.shape[0], 16)])
     sweep = {}
     with torch.no_grad():
-        torch.set_num_threads(min(32, cores))
+        torch.set_num_threads(min(32, cores, R.host_cpu_budget()[1]))
         R.encode_images(sd, sp, x[:2], heads=16, patch=14, num_layers=24)                  # warm-up (thread pool, allocator, page-in)
-        for th in sorted({t for t in (32, 64, 128, cores) if t <= cores} or {cores}):     # ascending; stops once more threads clearly lose
+        for th in sorted({t for t in (R.host_cpu_budget()[1], 32, 64, 128, cores) if t <= cores} or {cores}):     # (the cgroup quota first) ascending; stops once more threads clearly lose
             torch.set_num_threads(th)
             t0 = time.time()
             enc(x[:4])
@@ -321,10 +344,10 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
                 break
         threads = min(sweep, key=sweep.get)
         torch.set_num_threads(threads)
-        # ALL host cores: one fp32 forward stops scaling at `threads` threads, so the slice is dealt in batches of 4 frames to up to
-        # 16 worker processes of 16 threads each (oracle/torch_ref.parallel_plan / encode_frames_u8_parallel: same arithmetic per frame; weights, frames
-        # and the output in shared memory; the spawn + torch import of the workers is inside the timed region).  The pool's hosts show 256 cores but
-        # run the container under a cgroup CPU quota (reported as `cpu_quota_cores`): the workers cannot burn more than that, whatever they are given.
+        # ALL cores the process may use: the pool's hosts show 256 cores but run the container under a cgroup CPU quota of 16
+        # (reported as `cpu_quota_cores`; tools/probe_host.py: 15.5 cores busy whatever is asked for), so the slice is dealt in batches of 4 frames to
+        # one single-threaded worker process per usable core (oracle/torch_ref.parallel_plan / encode_frames_u8_parallel: same arithmetic per frame;
+        # 4.7 core-seconds per frame against 8-9 for multi-threaded forwards whose waiting threads burn the quota; worker start-up inside the timed region)
         workers, wthreads = R.parallel_plan(n_cpu_frames, batch=4)
         t0 = time.time()
         feats = R.encode_frames_u8_parallel(sd, sp, u8, workers=workers, threads=wthreads, batch=4)      # the 64-frame slice = C1's encode
@@ -672,26 +695,13 @@ def main():
     if a.with_captions and full and world == 1 and config == "C3":
         # what the metric leaves out (SURVEY 8(f).1 "the true wall-clock dominator"), measured once on this code: the same step with the HIP
         # 7B model as the chunk captioner.  Separate object; `value` above is the headline metric and does not contain it.
-        pipe.captioner = TimedCaptioner(pipe.model)
-        pipe.step()                                              # warm-up: BatchDecoder's cache allocation, graph capture
-        pipe.captioner = cp = TimedCaptioner(pipe.model)
-        torch.cuda.synchronize(); t0c = time.perf_counter()
-        for _ in range(a.with_captions):
-            pipe.step()
-        torch.cuda.synchronize(); dtc = time.perf_counter() - t0c
-        r, k = cp.rec, a.with_captions
-        out["product"] = dict(
-            product_frames_per_s=round(n_total * k / dtc, 2), ms_per_step=round(dtc / k * 1e3, 1), steps=k,
-            what="the C3 step with the HIP LongVA-7B-shape model as chunk captioner + merge summariser (reference utiles.py:539-559,591-607; "
-                 "batched: llm.BatchDecoder, temperature 0.1, 128 new tokens): encode + caption + select + retrieve + answer prefill",
-            chunks_per_step=r["chunks"] // k, prompt_tokens_per_chunk=r["prompt_tokens"] // max(r["chunks"], 1),
-            caption_prefill_s_per_step=round(r["prefill_s"] / k, 3), caption_decode_s_per_step=round(r["decode_s"] / k, 3), summary_s_per_step=round(r["summary_s"] / k, 3),
-            caption_prefill=dict(bound="mfma", achieved=round(r["prefill_flop"] / max(r["prefill_s"], 1e-9) / 1e12, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s",
-                                 frac=round(r["prefill_flop"] / max(r["prefill_s"], 1e-9) / 1e12 / MFMA_PEAK_TF, 4)),
-            caption_decode=dict(bound="hbm", achieved=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
-                                tokens_per_s_aggregate=round(r["new_tokens"] / max(r["decode_s"], 1e-9), 1), ms_per_decode_step=round(r["decode_s"] / max(r["decode_steps"], 1) * 1e3, 2)))
-        pipe.captioner = None
+        try:
+            out["product"] = measure_product(pipe, a.with_captions, n_total)
+        except Exception as e:                                   # the side measurement must never take the headline line with it
+            out["product"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        finally:
+            pipe.captioner = None
+            torch.cuda.empty_cache()
     if not a.no_cpu_baseline and world == 1 and config in ("C2", "C3"):
         out["cpu_baseline"] = cpu_baseline(pipe, a.cpu_frames, max((i[0] + 1 for i in km_infos[-1:]), default=3))
     print(json.dumps(out))

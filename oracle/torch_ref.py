@@ -116,20 +116,21 @@ def host_cpu_budget():
 
 
 def parallel_plan(n_frames, batch=4):
-    """(workers, threads per worker) for encode_frames_u8_parallel on this host.  Measured on the pool's 256-core hosts (tools/probe_host.py,
-    profiles/r04_run4_host_probe.md): ONE fp32 forward is fastest at 32 threads (0.63 s/frame; 64 threads: 1.06), many small workers are much better -
-    8 x 16 threads 0.29 s/frame, 16 x 16 threads 0.15 s/frame incl. worker start-up - so: 16 threads per worker, up to 16 workers."""
-    import os
-    cores = os.cpu_count() or 1
-    if cores < 32:
-        return 1, cores
-    return max(1, min(16, cores // 16, (n_frames + batch - 1) // batch)), 16
+    """(workers, threads per worker) for encode_frames_u8_parallel on this host: as many single-threaded workers as the process may burn cores
+    (host_cpu_budget: the cgroup quota, 16 on the pool's 256-core hosts).  Measured there (tools/probe_host.py, profiles/r04_run4_host_probe.md): the
+    quota is what binds (15.5 cores busy whatever is asked for), so the plan that wastes the least CPU time wins - 16 workers x 1 thread 4.7 core-s per
+    frame (0.31 s/frame incl. worker start-up on 64 frames), 1 x 16 threads 8.1, 16 x 16 threads 9.0 (threads waiting at barriers burn the quota)."""
+    _, usable = host_cpu_budget()
+    workers = max(1, min(usable, (n_frames + batch - 1) // batch))
+    return workers, max(1, usable // workers)
 
 
 def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8, heads=16, patch=14, num_layers=24):
     """uint8 [N,H,W,3] (numpy) -> fp32 [N, P, d_out]: preprocess_u8 + encode_images in batches of `batch`, the batches dealt round-robin to
     `workers` spawned processes of `threads` threads each (weights, frames and the output live in shared memory)."""
+    import os
     import torch.multiprocessing as mp
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")          # (inherited by the workers) waiting threads sleep instead of burning a CPU quota
     frames = torch.from_numpy(u8).share_memory_()
     sv = {k: v.detach().float().cpu().share_memory_() for k, v in sd_vit.items()}
     sp = {k: v.detach().float().cpu().share_memory_() for k, v in sd_proj.items()}

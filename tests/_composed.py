@@ -122,8 +122,9 @@ def build(n_frames, mem, period, micro_batch, cpu_workers=1, cpu_batch=8):
     t_hip = time.time()
     # ---- CPU path: fp32 encode (oracle/torch_ref), same policy functions, oracle providers ----
     cores = os.cpu_count() or 1
-    workers, threads = (1, min(32, cores)) if cpu_workers <= 1 else R.parallel_plan(n_frames, batch=cpu_batch)
-    torch.set_num_threads(min(32, cores))
+    usable = R.host_cpu_budget()[1]                                 # cores the process may really burn (cgroup quota: 16 on the pool's 256-core hosts)
+    workers, threads = (1, min(32, usable)) if cpu_workers <= 1 else R.parallel_plan(n_frames, batch=cpu_batch)
+    torch.set_num_threads(min(32, usable))
     ref = R.encode_frames_u8_parallel(sd_vit, sd_proj, u8, workers=workers, threads=threads, batch=cpu_batch)
     t_enc = time.time()
     rec_cpu = {}
@@ -199,8 +200,7 @@ def prefill_both(c2, layers=2, vocab=8192, row_chunk=None):
     img = torch.cat([c2["ref"][f].reshape(-1, 3584) for f in frames])
     emb32 = torch.cat([table[ids[:p]], img, table[ids[p + 1:]]])
     sd32 = {k: v.float().cpu() for k, v in sd.items()}
-    if row_chunk:
-        torch.set_num_threads(min(64, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, R.host_cpu_budget()[1]))
     with torch.no_grad():
         ref = R.qwen2_logits(sd32, emb32, heads=cfg.heads, kv_heads=cfg.kv_heads, layers=layers, head_dim=cfg.head_dim, theta=cfg.rope_theta, eps=cfg.eps,
                              last_only=True, head_chunk=None if row_chunk else 4, row_chunk=row_chunk)

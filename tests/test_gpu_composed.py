@@ -40,12 +40,11 @@ def c1():
     reseed = [0] * (10 * K)
     red, labels, info = U.weighted_kmeans_feature(feats, K, init_idx=init_idx, reseed_idx=reseed, return_info=True)
     # ---- CPU path ----
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    sv = {k: v.float().cpu() for k, v in sd_vit.items()}
-    sp = {k: v.float().cpu() for k, v in sd_proj.items()}
-    with torch.no_grad():
-        ref = torch.cat([R.encode_images(sv, sp, torch.from_numpy(R.preprocess_u8(u8[i:i + 8])), heads=16, patch=14, num_layers=24)
-                         for i in range(0, N_FRAMES, 8)])
+    # fp32 host encode: one single-threaded worker process per core the container may burn (oracle/torch_ref.parallel_plan: the pool's hosts run
+    # under a 16-core cgroup quota; same arithmetic per frame as the in-process loop it replaces)
+    torch.set_num_threads(min(32, R.host_cpu_budget()[1]))
+    workers, threads = R.parallel_plan(N_FRAMES, batch=4)
+    ref = R.encode_frames_u8_parallel(sd_vit, sd_proj, u8, workers=workers, threads=threads, batch=4)
     Xr = ref.reshape(N_FRAMES, -1).numpy()
     o = oracle.kmeans_fit(Xr, K, init_idx.numpy().astype(np.int32), np.asarray(reseed, np.int32))
     d2 = oracle.kmeans_dist2(Xr, o["centroids"])

@@ -36,7 +36,7 @@ from tests._composed import QUESTION, build, crossfade_stream, prefill_both   # 
 
 @pytest.fixture(scope="module")
 def c2():
-    return build(N_FRAMES, MEM, period=16, micro_batch=88)                         # 5.5 cross-fades of 16 frames: no trivially separable scene cuts
+    return build(N_FRAMES, MEM, period=16, micro_batch=88, cpu_workers=16, cpu_batch=4)                         # 5.5 cross-fades of 16 frames: no trivially separable scene cuts
 
 
 def test_c2_short_memory_frames_identical(c2):

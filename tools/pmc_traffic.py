@@ -29,7 +29,7 @@ for fam, pat in FAMILIES.items():
         continue
     res[fam] = dict(launches=nf, fetch_kb_per_launch=f / nf, write_kb_per_launch=(w / nw if nw else 0.0),
                     hbm_bytes_per_launch=(2.0 * f / nf + (w / nw if nw else 0.0)) * 1024)
-json.dump(dict(command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --decode-tokens 0 (two separate passes; "
+json.dump(dict(command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --decode-tokens 0 --with-captions 0 (two separate passes; "
                        "every launch of the warm-up and the two timed steps is counted: a warm multi-step run, averaged per launch)",
                correction="gfx950: FETCH_SIZE (KiB) x2 (calibrated on km_update: 2 x 826,624 KiB = T*D*2 bytes); WRITE_SIZE (KiB) as reported", kernels=res),
           open(sys.argv[3], "w"), indent=1)
