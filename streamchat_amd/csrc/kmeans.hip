@@ -481,17 +481,26 @@ __global__ void km_labels_in(const int64_t* __restrict__ labels, int* __restrict
     if (t < T) { const int64_t l = labels[t]; labels32[t] = (l < 0 || l >= K) ? 0 : (int)l; }
 }
 
-template <typename Tag>
-__global__ void km_init(const void* __restrict__ X, const int* __restrict__ init_idx, float* __restrict__ C, KmState* st,
-                        int T, int64_t D, int K) {
-    const size_t n = (size_t)K * (size_t)D;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 0; st->exit_iter = 0; st->cur = 0; st->reseed_pos = 0; st->status = 0; st->n_empty = 0; }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i / (size_t)D);
-        const size_t j = i - (size_t)k * (size_t)D;
-        int r = init_idx[k];
-        if (r < 0 || r >= T) r = 0;
-        C[i] = sc_load1<Tag>(X, (size_t)r * (size_t)D + j);
+// C[k] = X[init_idx[k]] as fp32 (+ state reset).  Grid (column blocks, K): 8 consecutive columns per thread as one 16-byte load and two 16-byte
+// stores where D allows it (round 4: the element-wise version spent 49 us on a 64-bit division per element; 41 MB at K = 5)
+template <typename Tag, bool VEC>
+__global__ __launch_bounds__(256) void km_init(const void* __restrict__ X, const int* __restrict__ init_idx, float* __restrict__ C, KmState* st,
+                                                 int T, int64_t D, int K) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { st->done = 0; st->exit_iter = 0; st->cur = 0; st->reseed_pos = 0; st->status = 0; st->n_empty = 0; }
+    const int k = blockIdx.y;
+    int r = init_idx[k];
+    if (r < 0 || r >= T) r = 0;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (j >= D) return;
+    float v[8];
+    if (VEC) {
+        sc_load8<Tag>(X, (size_t)r * (size_t)D + (size_t)j, v);
+        sc_f4* dst = reinterpret_cast<sc_f4*>(C + (size_t)k * (size_t)D + (size_t)j);
+        dst[0] = sc_f4{v[0], v[1], v[2], v[3]};
+        dst[1] = sc_f4{v[4], v[5], v[6], v[7]};
+    } else {
+        for (int e = 0; e < 8; ++e)
+            if (j + e < D) C[(size_t)k * (size_t)D + (size_t)(j + e)] = sc_load1<Tag>(X, (size_t)r * (size_t)D + (size_t)(j + e));
     }
 }
 
@@ -575,7 +584,11 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     const int64_t nch = (D + CH - 1) / CH;
     const size_t I = (size_t)T * K;
     const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    hipLaunchKernelGGL((km_init<Tag>), dim3(1024), dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+    {
+        const dim3 igrid((unsigned)((D + 2047) / 2048), (unsigned)K);
+        if (vec) hipLaunchKernelGGL((km_init<Tag, true>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+        else hipLaunchKernelGGL((km_init<Tag, false>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+    }
     const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
     const dim3 rgrid((unsigned)((I + 255) / 256), NSEG);
     for (int it = 0; it < max_iter; ++it) {
