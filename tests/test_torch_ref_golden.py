@@ -72,3 +72,29 @@ def test_preprocess_restatement_matches_hf_processor_golden():
     h = R.preprocess_u8(u8).astype(np.float16)
     assert np.array_equal(h[:, :, ::8, ::8].view(np.uint16), d["sub"].view(np.uint16))
     assert h.astype(np.float64).sum() == float(d["sum64"])
+
+
+def test_parallel_host_encode_equals_the_in_process_loop_and_plans_inside_the_cpu_budget():
+    """oracle/torch_ref.encode_frames_u8_parallel (the all-cores fp32 reference encode of bench.py's cpu_baseline and of the composed-parity tests):
+    spawned single-threaded workers give the in-process result bit for bit (a batch is the same frames wherever it runs), and parallel_plan never
+    asks for more than host_cpu_budget() allows (cgroup quota / affinity: the pool's GPU boxes show 256 cores and grant 16)."""
+    import numpy as np
+    import torch
+    from oracle import torch_ref as R
+    from streamchat_amd import vision as V
+    present, usable = R.host_cpu_budget()
+    assert 1 <= usable <= present
+    for n in (1, 7, 64, 440):
+        w, t = R.parallel_plan(n, batch=4)
+        assert 1 <= w <= max(1, min(usable, (n + 3) // 4)) and 1 <= w * t <= max(usable, 1)
+    cfg = V.CLIPVisionConfigLite(hidden=64, layers=3, heads=2, intermediate=128, patch=14, image_size=56)
+    sd = V.random_clip_state_dict(cfg, seed=0, device="cpu", std=0.08)
+    sp = V.random_projector_state_dict(64, 96, seed=1, device="cpu", std=0.08)
+    u8 = np.random.default_rng(0).integers(0, 256, (10, 56, 56, 3), dtype=np.uint8)
+    one = R.encode_frames_u8_parallel(sd, sp, u8, workers=1, threads=1, batch=4, heads=2, patch=14, num_layers=3)
+    two = R.encode_frames_u8_parallel(sd, sp, u8, workers=2, threads=1, batch=4, heads=2, patch=14, num_layers=3)
+    assert one.shape == (10, 16, 96) and torch.equal(one, two)
+    with torch.no_grad():
+        ref = torch.cat([R.encode_images({k: v.float() for k, v in sd.items()}, {k: v.float() for k, v in sp.items()}, torch.from_numpy(R.preprocess_u8(u8[i:i + 4])),
+                                         heads=2, patch=14, num_layers=3) for i in range(0, 10, 4)])
+    assert torch.equal(one, ref)
