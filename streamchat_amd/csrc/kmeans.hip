@@ -23,7 +23,7 @@ namespace {
 
 constexpr int CH = 512;      // columns per chunk = 64 lanes x 8 elements
 constexpr int NSEG = 32;     // fp64 segments
-constexpr int WPB = 4;       // waves per block in the streaming kernels
+constexpr int WPB = 4;       // waves per block in the streaming kernels (2 / 8: +-0.3 %, profiles/r04_run9_kmeans_knobs.md)
 typedef float sc_f2 __attribute__((ext_vector_type(2)));
 
 struct KmState {
