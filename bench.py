@@ -235,7 +235,7 @@ class Pipeline:
                                                                             cache=U.CaptionEmbeddingCache())
             wanted = list(short) + list(path)
         wanted = mem.broadcast_refs(wanted)
-        sel = mem.fetch(wanted, dst=0, mode="allgather")
+        sel = mem.fetch(wanted, dst=0)
         self.last = dict(tree=tree, wanted=[mem.frames_of(r) for r in wanted], path_text=path_text, related=related, mem=mem)
         if ctx.is_root:
             self.last["image_embeddings"] = image_embeddings = sel.reshape(-1, sel.shape[-1])
@@ -281,7 +281,7 @@ class Pipeline:
                 path, path_text = U.fast_search_tree_multi_modal_with_embedding(tree, self.question, feats, self.colbert, self.tok, cache=cache)
                 wanted = list(short) + list(path)
             wanted = mem.broadcast_refs(wanted)
-            sel = mem.fetch(wanted, dst=0, mode="allgather")
+            sel = mem.fetch(wanted, dst=0)
             rec = dict(wanted=[mem.frames_of(x) for x in wanted], path_text=path_text, top=[(n.depth, n.centroids.rows) for n in tree])
             if ctx.is_root and self.model is not None:
                 self.prefill(sel.reshape(-1, sel.shape[-1]), path_text[-1])
@@ -662,11 +662,16 @@ def main():
         out["scaling_note"] = (
             f"encode (ViT-L + projector) and chunk captions are rank-local: {n_total} frames over {world} GPUs, no data-path collective; "
             "select / retrieve run on the whole stream from metadata identical on every rank (one merge k-means on the rank owning the "
-            "group, rows it lacks arrive point to point); ONE all-gather moves the selected rows; the 7B prefill"
+            "group, rows it lacks arrive point to point); the selected rows are GATHERED TO RANK 0 (one batch of point-to-point sends into "
+            "their final position: only rank 0 allocates, only the rows it lacks move - `collective`); the 7B prefill"
             + (" + decode" if config == "C5" else "") + " is SERIAL on rank 0 (single-GPU, no TP) and its context (~49 k tokens) does not "
             "grow with the stream, so `value` scales with the frames per step while ms_per_step stays that of the serial tail + one "
             "rank's encode; read encode scaling from encode_frames_per_s against encode_frames_per_s_1gpu_same_job (rank 0 encoding its "
             "shard alone, other ranks idle at a barrier) or against the N = 1 record")
+    if world > 1 and pipe.last.get("mem") is not None:         # row bytes that crossed ranks in the LAST step (merge-group pieces + selected rows), from the Refs
+        tr = pipe.last["mem"].traffic
+        out["collective"] = dict(kind="gather-to-root (batch_isend_irecv)", fetches_with_traffic=tr["fetches"], bytes_moved_last_step=tr["bytes_moved"],
+                                 note="round 4's all-gather of the selected rows moved world x max-rows-per-rank slots to EVERY rank")
     out.update(config=dict(workload=names[config], context_tokens=pipe.last.get("context"), frames_total=n_total, frames_rank0=pipe.n,
                            frames_per_gpu=per_gpu, micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""),
                            weights="random-init", launcher="self (bare command)" if os.environ.get("SC_BENCH_SELF_LAUNCHED") == "1" else

@@ -74,29 +74,44 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
 
 // ------------------------------------------------------------------------------------------------------------------
 // Decode attention (few query rows against a long KV cache; batch-1 decode packs the G query heads of a KV group as G <= 16 query
-// rows of one "head", llm.py _decode_one / DecodeGraph): HBM-bound, 2.8 GB of K/V per token at a 49 k context.  k_attn above serves
-// this shape with one workgroup per (head, split) in which only wave 0 has queries and ONE 64-row tile is in flight behind a block
-// barrier (4.4 TB/s).  Here every WAVE is an independent stream over its own contiguous run of 32-row chunks - no block barrier in
-// the loop - and keeps about three chunks (48 KB) in flight:
-//   K: straight from global memory into MFMA A-operand registers (a 16 x 32 fragment is 16 bytes per lane; each element is used
-//      once, so staging it in LDS would only add traffic), two register sets, re-issued as soon as the S MFMAs have consumed them;
-//   V: buffer_load ... lds into a per-wave ring of three 8 KiB stages (P.V needs V transposed: ds_read_b64_tr_b16), completion by a
-//      counted s_waitcnt vmcnt - the loads of a wave retire in order;
+// rows of one "head", llm.py _decode_one / DecodeGraph): HBM-bound, 2.8 GB of K/V per token at a 49 k context.  Every WAVE is an
+// independent stream over its own contiguous run of 32-row chunks - no block barrier in the loop.
+//
+// Round 5: BOTH operands reach the wave by LDS-DMA (buffer_load ... lds) into per-wave rings of DEC_PD stages, every wait is a
+// hand-counted s_waitcnt vmcnt and every LDS read is inline asm.  The round-3 kernel loaded K straight into MFMA operand registers
+// with the buffer-load builtin next to the V DMA: hipcc cannot count a register load's position in a queue that also holds LDS-DMA
+// ops across a loop back-edge, so it put `s_waitcnt vmcnt(0)` in front of the first S MFMA of every trip - the whole prefetch queue
+// drained once per two chunks (22.9 us per layer at 49 k = 4.4 TB/s, the same time as the one-tile-in-flight tile kernel, which is
+// what gave it away; cdna guide 5.x "mixing load KINDS in one k-loop mis-waits").
+//   K: rows of 256 B land in LDS row-major with the 16-byte piece index XORed with (row & 15) on the SOURCE side (an LDS-DMA image is
+//      lane-linear), read back as MFMA A fragments with ds_read_b128 - conflict-free (a 16-lane service group holds 16 distinct rows);
+//      global side: every DMA instruction fetches 4 whole rows = 8 full 128-B lines (the register path fetched 16 rows x 64 B);
+//   V: as before, swizzled rows read with ds_read_b64_tr_b16 (P.V needs V transposed);
+//   queue order per chunk c: K(c+PD) is requested as soon as the S MFMAs have read K(c)'s fragments, V(c+PD) as soon as the transpose
+//   reads of V(c) have returned, so each ring needs only DEC_PD stages: 2 x 16 KiB per wave, 128 KiB per workgroup;
 //   rows past the wave's range are outside the buffer resource's extent: zeros, no memory traffic (the row part of every address
 //   stays in the VGPR offset, which is what the range check covers).
+// The MFMA operands are element for element those of the round-3 kernel: results are bit-identical to it.
 // Exact online softmax per chunk (the loop is bandwidth-bound, the VALU work is free).  The four waves of a workgroup cover four
 // consecutive quarters of one split; they merge their (O, m, l) through LDS at the end, so a workgroup leaves ONE partial per split
-// in the layout k_attn_combine reads: half as many partials as before at the same number of waves streaming.
+// in the layout k_attn_combine reads.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DCH = 32;                            // kv rows per chunk
-constexpr int DEC_STAGES = 3;
+#ifndef SC_DEC_PD
+#define SC_DEC_PD 2                                // chunks in flight per wave = stages of the K and of the V ring
+#endif
+constexpr int DEC_PD = SC_DEC_PD;
+static_assert(DEC_PD >= 1 && 16 * DEC_PD - 8 < 64, "vmcnt is a 6-bit counter");
 
 template <int DH>
 __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                                         const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
                                                         const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one V chunk (8 KiB at Dh = 128)
+    static_assert(DH == 128, "the K ring is laid out for 256-byte rows");
+    constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one K or V chunk (8 KiB at Dh = 128)
+    constexpr int WAVE_LDS = 2 * DEC_PD * CHB;                                          // [K stages | V stages] of one wave
+    constexpr int CNT = 16 * DEC_PD - 8;                                                // vm ops younger than the chunk part being waited for (see the loop)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rl = lane & 15, g = lane >> 4;
@@ -110,42 +125,53 @@ __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restri
     const int c_lo = min(s_lo + wave * cpw, s_hi), c_hi = min(c_lo + cpw, s_hi);
     const int row_end = min(c_hi * DCH, kv_valid);                                      // rows of this wave: [c_lo * 32, row_end)
 
-    // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements)
-    sc_h8 qf[DS];
+    // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements): inline asm, so that no compiler-tracked vector
+    // load is pending when the DMA queue starts (see the header); waited for together with the first K chunk
+    sc_u4 qf[DS];
     {
         const int qr = rl < Sq ? rl : Sq - 1;
         const _Float16* qp = Q + (size_t)b * (size_t)q_bs + (size_t)qr * (size_t)ldq + h * q_hs + g * 8;
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const sc_h8*>(qp + ds * 32);
+        for (int ds = 0; ds < DS; ++ds) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[ds]) : "v"(qp), "n"(ds * 64) : "memory");
     }
     const _Float16* kbase = Kp + (size_t)b * Skv * (size_t)ldk + hk * DH;
     const _Float16* vbase = Vp + (size_t)b * Skv * (size_t)ldv + hk * DH;
-    const int k_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldk + DH) * 2u) : 0;
-    const int v_ext = row_end > 0 ? (int)(((unsigned)(row_end - 1) * (unsigned)ldv + DH) * 2u) : 0;
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kbase), 0, c_lo < c_hi ? k_ext : 0, 0x00020000);
-    // per-lane offsets inside a chunk: K fragment (kvb, ds) = row kvb*16 + rl, 16 bytes at element (ds*4 + g)*8;
-    // V granule j*64 + lane = row j*4 + (lane>>4), 16-byte slot (lane&15) ^ ((row&7)<<1)   (the swizzle the transpose reads below undo)
-    unsigned k_vo[2], v_vo[8];
+    const bool any = c_lo < c_hi;
+    const int k_ext = (any && row_end > 0) ? (int)(((unsigned)(row_end - 1) * (unsigned)ldk + DH) * 2u) : 0;
+    const int v_ext = (any && row_end > 0) ? (int)(((unsigned)(row_end - 1) * (unsigned)ldv + DH) * 2u) : 0;
+    // per-lane source offsets inside a chunk.  DMA granule j * 64 + lane lands at LDS byte (j * 64 + lane) * 16 = row j * 4 + (lane >> 4),
+    // 16-byte slot lane & 15; it fetches the piece (lane & 15) ^ (row & 15) of that K row / (lane & 15) ^ ((row & 7) << 1) of that V row
+    unsigned k_vo[8], v_vo[8];
 #pragma unroll
-    for (int kvb = 0; kvb < 2; ++kvb) k_vo[kvb] = ((unsigned)(kvb * 16 + rl) * (unsigned)ldk + (unsigned)(g * 8)) * 2u;
+    for (int j = 0; j < 8; ++j) {
+        const int r = j * 4 + (lane >> 4);
+        k_vo[j] = ((unsigned)r * (unsigned)ldk + (unsigned)(((lane & 15) ^ (r & 15)) * 8)) * 2u;
+        v_vo[j] = ((unsigned)r * (unsigned)ldv + (unsigned)(((lane & 15) ^ ((r & 7) << 1)) * 8)) * 2u;
+    }
+    char* kring = smem + wave * WAVE_LDS;
+    char* vring = kring + DEC_PD * CHB;
+    const unsigned kbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * WAVE_LDS);
+    const unsigned vbase_lds = kbase_lds + (unsigned)(DEC_PD * CHB);
+    // read offsets: K fragment (kvb, ds) of lane (rl, g) = row kvb * 16 + rl, piece ds * 4 + g -> slot piece ^ rl (kvb: +4096 bytes)
+    unsigned k_off[DS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int vr = j * 4 + (lane >> 4); v_vo[j] = ((unsigned)vr * (unsigned)ldv + (unsigned)(((lane & 15) ^ ((vr & 7) << 1)) * 8)) * 2u; }
-    char* vring = smem + wave * (DEC_STAGES * CHB);
-    const unsigned vbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (DEC_STAGES * CHB));
+    for (int ds = 0; ds < DS; ++ds) k_off[ds] = (unsigned)(rl * VROW + (((ds * 4 + g) ^ rl) << 4));
     const int vrow = 4 * g + (rl >> 2);
-    int v_off[DB];
+    unsigned v_off[DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) v_off[db] = vrow * VROW + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8;
+    for (int db = 0; db < DB; ++db) v_off[db] = (unsigned)(vrow * VROW + ((db ^ (vrow & 7)) << 5) + (rl & 3) * 8);
 
-    auto issue = [&](int c, sc_u4 (&kr)[2][DS]) {              // 2*DS register loads + 8 LDS-DMA = 16 vm ops at Dh = 128, in this order
-        const unsigned ro_k = (unsigned)c * (unsigned)(DCH * ldk * 2), ro_v = (unsigned)c * (unsigned)(DCH * ldv * 2);
+    auto issue_k = [&](int c) {                                  // 8 LDS-DMA ops
+        const unsigned ro = (unsigned)c * (unsigned)(DCH * ldk * 2);
+        char* dst = kring + (c % DEC_PD) * CHB;
 #pragma unroll
-        for (int kvb = 0; kvb < 2; ++kvb)
+        for (int j = 0; j < 8; ++j) lds_load16(kbase, c < c_hi ? k_ext : 0, dst + j * 1024, ro + k_vo[j], 0);
+    };
+    auto issue_v = [&](int c) {                                  // 8 LDS-DMA ops
+        const unsigned ro = (unsigned)c * (unsigned)(DCH * ldv * 2);
+        char* dst = vring + (c % DEC_PD) * CHB;
 #pragma unroll
-            for (int ds = 0; ds < DS; ++ds) kr[kvb][ds] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (int)(ro_k + k_vo[kvb] + ds * 64), 0, 0);
-        char* dst = vring + (c % DEC_STAGES) * CHB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds_load16(vbase, c < c_hi ? v_ext : 0, dst + j * 1024, ro_v + v_vo[j], 0);
+        for (int j = 0; j < 8; ++j) lds_load16(vbase, c < c_hi ? v_ext : 0, dst + j * 1024, ro + v_vo[j], 0);
     };
 
     sc_f4 o[DB];
@@ -153,85 +179,90 @@ __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restri
     for (int i = 0; i < DB; ++i) o[i] = sc_f4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    auto compute = [&](int c, sc_u4 (&kr)[2][DS], auto reissue) {
-        // ---- S^T = K . Q^T for the 32 rows (this consumes the K registers) ----
-        sc_f4 s[2];
+    // The vm queue of a wave, in issue order:  [q x DS]  K(c0) V(c0) ... K(c0+PD-1) V(c0+PD-1)   then per chunk c:  K(c+PD)  V(c+PD).
+    // When S(c) starts, the ops younger than K(c) are V(c), K/V(c+1 .. c+PD-1) = 16 PD - 8; when P.V(c) starts, the ops younger than
+    // V(c) are K/V(c+1 .. c+PD-1) and K(c+PD) = 16 PD - 8 as well: one constant serves both waits.
+    if (any) {
 #pragma unroll
-        for (int kvb = 0; kvb < 2; ++kvb) {
-            s[kvb] = sc_f4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < DEC_PD; ++u) { issue_k(c_lo + u); issue_v(c_lo + u); }          // (past c_hi: zero extent -> no traffic)
+        for (int c = c_lo; c < c_hi; ++c) {
+            const unsigned stage = (unsigned)((c % DEC_PD) * CHB);
+            // ---- S^T = K . Q^T for the 32 rows ----
+            static_assert(DS == 4, "the fences below name 8 K fragments and 4 q fragments");
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : "n"(CNT) : "memory");
+            sc_u4 kf[2][DS];
+            const unsigned ka = kbase_lds + stage;
 #pragma unroll
-            for (int ds = 0; ds < DS; ++ds) s[kvb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, kr[kvb][ds]), qf[ds], s[kvb], 0, 0, 0);
-        }
-        // the MFMAs above have READ kr; make that visible to the scheduler before the registers are loaded again
-        asm volatile("" : "+v"(s[0]), "+v"(s[1]));
-        reissue();
-        // ---- exact online-softmax step ----
-        const int kv0 = c * DCH + g * 4;
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kvb = 0; kvb < 2; ++kvb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kvb][r] = (kv0 + kvb * 16 + r < row_end) ? s[kvb][r] : -INFINITY;
-                tmax = fmaxf(tmax, s[kvb][r]);
+            for (int ds = 0; ds < DS; ++ds) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][ds]) : "v"(ka + k_off[ds]));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][ds]) : "v"(ka + k_off[ds]), "n"(16 * VROW));
             }
-        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-        const auto bsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        tmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1])) * scale_log2;
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        l_run *= alpha;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]),
+                                                  "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]) :: "memory");
+            issue_k(c + DEC_PD);                                   // K(c)'s stage is free: its fragments are in registers
+            sc_f4 s[2];
 #pragma unroll
-        for (int db = 0; db < DB; ++db) o[db] *= alpha;
-        sc_h8 pf;
-        float ps = 0.f;
+            for (int kvb = 0; kvb < 2; ++kvb) {
+                s[kvb] = sc_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kvb = 0; kvb < 2; ++kvb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][r], scale_log2, -m_use));
-                ps += p;
-                pf[kvb * 4 + r] = (_Float16)p;
+                for (int ds = 0; ds < DS; ++ds)
+                    s[kvb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, kf[kvb][ds]), __builtin_bit_cast(sc_h8, qf[ds]), s[kvb], 0, 0, 0);
             }
-        l_run += ps;
-        // ---- O^T += V^T . P^T : the V chunk must have landed (everything issued after it may stay in flight: 16 vm ops per chunk) ----
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DS + 8) : "memory");
-        // The transpose reads are inline asm: behind a builtin LDS read hipcc puts s_waitcnt vmcnt(0) (the LDS-DMA of later chunks "may
-        // alias" it), which would drain the whole prefetch queue on every chunk.  The stages of the ring are disjoint by construction.
-        const unsigned sa = vbase_lds + (unsigned)((c % DEC_STAGES) * CHB);
-        sc_s4 lo[DB], hi[DB];
+            // ---- exact online-softmax step ----
+            const int kv0 = c * DCH + g * 4;
+            float tmax = -INFINITY;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[db]) : "v"(sa + (unsigned)v_off[db]));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[db]) : "v"(sa + (unsigned)v_off[db]), "n"(16 * VROW));
-        }
-        static_assert(DB == 8, "the lgkmcnt fence below names 16 registers");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
-                                              "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]));
+            for (int kvb = 0; kvb < 2; ++kvb)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            typedef short sc_s8 __attribute__((ext_vector_type(8)));
-            const sc_s8 v8 = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi[db][0], hi[db][1], hi[db][2], hi[db][3]};
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, v8), pf, o[db], 0, 0, 0);
-        }
-    };
-
-    // ---- the stream: chunks c_lo .. c_hi - 1; chunk c + 2 is requested right after the S MFMAs of chunk c ----
-    sc_u4 ka[2][DS], kb[2][DS];
-    if (c_lo < c_hi) {
-        issue(c_lo, ka);
-        issue(c_lo + 1, kb);                       // (past c_hi: zero extent -> no traffic)
-        for (int c = c_lo; c < c_hi; c += 2) {
-            compute(c, ka, [&] { issue(c + 2, ka); });
-            if (c + 1 < c_hi) compute(c + 1, kb, [&] { issue(c + 3, kb); });
-            else break;
+                for (int r = 0; r < 4; ++r) {
+                    s[kvb][r] = (kv0 + kvb * 16 + r < row_end) ? s[kvb][r] : -INFINITY;
+                    tmax = fmaxf(tmax, s[kvb][r]);
+                }
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+            const auto bsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1])) * scale_log2;
+            const float m_new = fmaxf(m_run, tmax);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o[db] *= alpha;
+            sc_h8 pf;
+            float ps = 0.f;
+#pragma unroll
+            for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvb][r], scale_log2, -m_use));
+                    ps += p;
+                    pf[kvb * 4 + r] = (_Float16)p;
+                }
+            l_run += ps;
+            // ---- O^T += V^T . P^T : V(c) must have landed ----
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+            const unsigned sa = vbase_lds + stage;
+            sc_s4 lo[DB], hi[DB];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[db]) : "v"(sa + v_off[db]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[db]) : "v"(sa + v_off[db]), "n"(16 * VROW));
+            }
+            static_assert(DB == 8, "the lgkmcnt fence below names 16 registers");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]),
+                                                  "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]) :: "memory");
+            issue_v(c + DEC_PD);                                   // V(c)'s stage is free
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                typedef short sc_s8 __attribute__((ext_vector_type(8)));
+                const sc_s8 v8 = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi[db][0], hi[db][1], hi[db][2], hi[db][3]};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, v8), pf, o[db], 0, 0, 0);
+            }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the ring is reused / the block ends
-    // ---- merge the four waves of the split through LDS (aliases the V rings: every wave is done with its own) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the rings are reused / the block ends
+    // ---- merge the four waves of the split through LDS (aliases the rings: every wave is done with its own) ----
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();
@@ -273,7 +304,7 @@ void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B
 
 void sc_attn_decode_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
                            const int32_t* kv_len, float* part, int nsplit, int q_hs, long q_bs, hipStream_t s) {
-    constexpr int LDS_DEC = 4 * DEC_STAGES * DCH * 128 * 2;
+    constexpr int LDS_DEC = 4 * 2 * DEC_PD * DCH * 128 * 2;          // 4 waves x (K ring + V ring) x DEC_PD stages of 8 KiB
     static bool attr_done[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -257,6 +257,224 @@ __global__ __launch_bounds__(512) void k_decode_qkv(const _Float16* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: shape-specialised decode projections - K = NS * 512 and the workgroup size are template parameters, the kernel body is
+// straight-line code (every loop below unrolls completely), all loads are ordinary loads in the program order the queue should have.
+// What the generic kernels above leave to hipcc, and what it does with it (the .s of the round-4 library):
+//  * `#pragma unroll N` over the weight loop with a run-time trip count: the trip % N remainder is peeled into a one-slice-per-trip loop
+//    IN FRONT of the unrolled body - load, s_waitcnt vmcnt(0), dot, repeat: the down projection (37 slices, N = 8) opened every wave
+//    with five fully serialised memory round trips, the o projection (7 slices, N = 4) ran three; inside the unrolled body the
+//    activation slice is loaded BEHIND the weights it multiplies (vmcnt retires in order: the first dot drains the whole batch) and no
+//    batch is requested before the previous one has been consumed;
+//  * `bias ? bias[n] : 0` / `res ? res[n] : 0`: each load in its own branch with `s_waitcnt vmcnt(0)` behind it - one (o) or two (down)
+//    round trips before the first weight byte is requested;
+//  * the fused RMSNorm reads gamma only after its first barrier (a second dependent latency), reads x twice, and - in-order again -
+//    cannot see x before the weight slices requested ahead of it have landed.
+// Two attempts to fix this inside the generic kernels failed on the compiler: explicit two-buffer batching in plain C++ (with loads
+// behind wave-uniform branches the wait-count pass falls back to vmcnt(0) at every first use) and inline-asm loads with hand-counted
+// waits (hipcc merges the buffers of different control-flow arms with v_mov copies placed right behind the loads: it copies registers
+// whose data is still in flight).  Without control flow neither problem exists: the queue of a wave is, in issue order,
+//     [bias / residual]  [x (and gamma) chunks of this thread]  [weight batch 0]  |  per batch b: [batch b + 1]
+// x is waited for with batch 0 outstanding (the norm's reduce -> barrier -> normalise -> barrier chain runs under the stream's first
+// latency), batch b with batch b + 1 outstanding, and hipcc's own counted waits are exact.  The activation vector is always staged
+// in LDS (normalised or copied), so the stream has no other vector-memory access in it.  Each lane adds its slices in ascending
+// order, the norm sums its chunks in the order of the generic kernel: all results are bit-identical to the generic kernels'.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NS, int WPB, bool NORM>
+struct XStageU {
+    static constexpr int T = 64 * WPB, K = NS * 512, CH = K / 8, NX = (CH + T - 1) / T;
+    static_assert(!NORM || (WPB == 4 && NX <= 2), "the norm's reduction order is that of 256 threads: thread t sums chunks t, t + 256");
+    sc_h8 xr[NX], gr[NORM ? NX : 1];
+    __device__ __forceinline__ void issue(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {                  // (a chunk past the end is clamped to the LAST chunk: loaded, processed and stored a second
+            const int k = (t + i * T) * 8, kc = k < K ? k : K - 8;      //  time with the same values - no load sits behind a condition hipcc could sink it into)
+            xr[i] = *reinterpret_cast<const sc_h8*>(x + kc);
+            if (NORM) gr[i] = *reinterpret_cast<const sc_h8*>(gamma + kc);
+        }
+    }
+    __device__ __forceinline__ void finish(float eps, _Float16* xn, float* red) {
+        const int t = threadIdx.x;
+        if (NORM) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if ((t + i * T) * 8 < K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss += (float)xr[i][e] * (float)xr[i][e];
+                }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+            if ((t & 63) == 0) red[t >> 6] = ss;
+            __syncthreads();
+            const float rstd = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)K + eps);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int k = (t + i * T) * 8, kc = k < K ? k : K - 8;
+                sc_h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)gr[i][e] * (float)(_Float16)((float)xr[i][e] * rstd));
+                *reinterpret_cast<sc_h8*>(xn + kc) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const int k = (t + i * T) * 8, kc = k < K ? k : K - 8; *reinterpret_cast<sc_h8*>(xn + kc) = xr[i]; }
+        }
+        __syncthreads();
+    }
+};
+
+// the weight stream of a wave: RPW rows (wp[r] already offset by lane * 8), NS slices in batches of UNR, two register buffers
+template <int RPW, int NS, int UNR>
+struct StreamU {
+    static constexpr int NBATCH = (NS + UNR - 1) / UNR;
+    sc_h8 buf[2][UNR][RPW];
+    template <int B>
+    __device__ __forceinline__ void load(const _Float16* const (&wp)[RPW]) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (B * UNR + u < NS) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) buf[B & 1][u][r] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp[r] + (B * UNR + u) * 512));
+            }
+    }
+    template <int B>
+    __device__ __forceinline__ void run(const _Float16* const (&wp)[RPW], const _Float16* xn, int lane, float (&acc)[RPW]) {
+        if constexpr (B < NBATCH) {
+            if constexpr (B + 1 < NBATCH) load<B + 1>(wp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (B * UNR + u < NS) {
+                    const sc_h8 xv = *reinterpret_cast<const sc_h8*>(xn + lane * 8 + (B * UNR + u) * 512);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2)
+                            acc[r] = __builtin_amdgcn_fdot2(sc_h2{buf[B & 1][u][r][e], buf[B & 1][u][r][e + 1]}, sc_h2{xv[e], xv[e + 1]}, acc[r], false);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            run<B + 1>(wp, xn, lane, acc);
+        }
+    }
+};
+
+template <bool SWIGLU, bool OUT_F32, bool NORM, int RPW, int NS, int WPB, int UNR>
+__global__ __launch_bounds__(64 * WPB) void k_gemv_u(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
+                                                     const _Float16* __restrict__ res, void* __restrict__ y, int N, const _Float16* __restrict__ gamma, float eps) {
+    constexpr int K = NS * 512;
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    _Float16* xn = reinterpret_cast<_Float16*>(gemv_smem);
+    float* red = reinterpret_cast<float*>(gemv_smem + (size_t)K * 2);
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * WPB + (int)(threadIdx.x >> 6)) * RPW;
+    const _Float16* wp[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) wp[r] = W + (size_t)(row0 + r < N ? row0 + r : N - 1) * (size_t)K + lane * 8;
+    // what the epilogue adds: requested first with branch-free loads (a null pointer reads W[0], the value is dropped), converted last
+    _Float16 eb_b[RPW], eb_r[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int n = row0 + r < N ? row0 + r : N - 1;
+        eb_b[r] = *(bias ? bias + n : W); eb_r[r] = *(res ? res + n : W);
+    }
+    XStageU<NS, WPB, NORM> xs;
+    xs.issue(x, gamma);
+    StreamU<RPW, NS, UNR> ws;
+    ws.template load<0>(wp);
+    __builtin_amdgcn_sched_barrier(0);
+    xs.finish(eps, xn, red);
+    // (no early exit for a wave past the last row: it streams row N - 1 again and stores nothing.  With `if (row0 >= N) return;` here
+    //  hipcc sinks the first weight batch below the staging's barriers, into the block that uses it)
+    float acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+    ws.template run<0>(wp, xn, lane, acc);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        // a use of the epilogue operands in THIS block: without it hipcc sinks their loads into the lane-0 block below, where each
+        // is a full memory round trip on the tail of the wave
+        asm volatile("" ::"v"((unsigned)__builtin_bit_cast(unsigned short, eb_b[r])), "v"((unsigned)__builtin_bit_cast(unsigned short, eb_r[r])));
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
+    }
+    if (lane == 0 && row0 < N) {
+        if (SWIGLU) {          // rows (g g u u): two outputs per 4 rows (RPW == 4)
+            const float g0 = acc[0], g1 = acc[RPW > 1 ? 1 : 0], u0 = acc[RPW > 2 ? 2 : 0], u1 = acc[RPW > 3 ? 3 : 0];
+            _Float16* o = reinterpret_cast<_Float16*>(y) + (row0 >> 1);
+            o[0] = (_Float16)(g0 / (1.0f + __expf(-g0)) * u0);
+            o[1] = (_Float16)(g1 / (1.0f + __expf(-g1)) * u1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int n = row0 + r;
+                if (n < N) {
+                    const float v = acc[r] + ((bias ? (float)eb_b[r] : 0.f) + (res ? (float)eb_r[r] : 0.f));
+                    if (OUT_F32) reinterpret_cast<float*>(y)[n] = v;
+                    else reinterpret_cast<_Float16*>(y)[n] = (_Float16)v;
+                }
+            }
+        }
+    }
+}
+
+// k_decode_qkv<true> for K = NS * 512 and four waves per workgroup (see k_gemv_u); queue: [bias pair] [x, gamma] [both weight rows,
+// all NS slices] [rotary table pair - its address needs pos[0], a scalar load: behind the weights, the stream does not wait for it]
+template <int NS>
+__global__ __launch_bounds__(256) void k_decode_qkv_u(const _Float16* __restrict__ Wq, const _Float16* __restrict__ Wkv, const _Float16* __restrict__ bq,
+                                                      const _Float16* __restrict__ bkv, const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
+                                                      float eps, _Float16* __restrict__ q_out, _Float16* __restrict__ cache, int ld,
+                                                      const int* __restrict__ pos, int Hq, int Hkv, int Dh,
+                                                      const float* __restrict__ tab_q, const float* __restrict__ tab_k, int tab_rows) {
+    constexpr int K = NS * 512;
+    const int lane = threadIdx.x & 63;
+    const int half = Dh >> 1;
+    const int task = blockIdx.x * 4 + (int)(threadIdx.x >> 6);            // (head, j) over q heads, then k heads, then v heads
+    const int ntask = (Hq + 2 * Hkv) * half;
+    const bool live = task < ntask;                                       // (dead waves of the last workgroup still take part in the staging's barriers)
+    const int hh = (live ? task : 0) / half, j = (live ? task : 0) - hh * half;
+    const _Float16 *w0, *b0;
+    int kind, h;                                                          // 0 = q, 1 = k, 2 = v
+    if (hh < Hq) { kind = 0; h = hh; w0 = Wq + (size_t)(h * Dh + j) * (size_t)K; b0 = bq ? bq + h * Dh + j : nullptr; }
+    else if (hh < Hq + Hkv) { kind = 1; h = hh - Hq; w0 = Wkv + (size_t)(h * Dh + j) * (size_t)K; b0 = bkv ? bkv + h * Dh + j : nullptr; }
+    else { kind = 2; h = hh - Hq - Hkv; w0 = Wkv + (size_t)((Hkv + h) * Dh + j) * (size_t)K; b0 = bkv ? bkv + (Hkv + h) * Dh + j : nullptr; }
+    const _Float16* wp[2] = {w0 + lane * 8, w0 + (size_t)half * (size_t)K + lane * 8};
+    extern __shared__ __attribute__((aligned(16))) char qkv_smem[];
+    _Float16* xn = reinterpret_cast<_Float16*>(qkv_smem);
+    float* red = reinterpret_cast<float*>(qkv_smem + (size_t)K * 2);
+    const _Float16 braw0 = *(b0 ? b0 : Wq), braw1 = *(b0 ? b0 + half : Wq);
+    XStageU<NS, 4, true> xs;
+    xs.issue(x, gamma);
+    StreamU<2, NS, NS> ws;
+    ws.template load<0>(wp);
+    __builtin_amdgcn_sched_barrier(0);
+    const int row = pos[0];
+    const int trow = row < 0 ? 0 : (row >= tab_rows ? tab_rows - 1 : row);      // the position lives in device memory: clamp to the table, never read past it
+    const float* t = (kind == 0 ? tab_q : tab_k) + (size_t)trow * (size_t)Dh;   // (a V row reads a table row it ignores)
+    const float tcs = t[j], tsn = t[half + j];
+    __builtin_amdgcn_sched_barrier(0);
+    xs.finish(eps, xn, red);
+    float acc[2] = {0.f, 0.f};                                            // (dead waves stream task 0 again and store nothing: see k_gemv_u)
+    ws.template run<0>(wp, xn, lane, acc);
+    float acc0 = acc[0], acc1 = acc[1];
+    asm volatile("" ::"v"((unsigned)__builtin_bit_cast(unsigned short, braw0)), "v"((unsigned)__builtin_bit_cast(unsigned short, braw1)), "v"(tcs), "v"(tsn));   // (see k_gemv_u)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { acc0 += __shfl_xor(acc0, m, 64); acc1 += __shfl_xor(acc1, m, 64); }
+    if (lane == 0 && live) {
+        const float bias0 = b0 ? (float)braw0 : 0.f, bias1 = b0 ? (float)braw1 : 0.f;
+        _Float16* dst = kind == 0 ? q_out + h * Dh + j : cache + (size_t)row * (size_t)ld + (kind == 1 ? 0 : Hkv * Dh) + h * Dh + j;
+        if (kind == 2) { dst[0] = (_Float16)(acc0 + bias0); dst[half] = (_Float16)(acc1 + bias1); return; }
+        const float a32 = acc0 + bias0, b32 = acc1 + bias1;
+        // fp32 fma FIRST, then the rounding to fp16 (see k_decode_qkv)
+        float ra = __builtin_fmaf(-b32, tsn, a32 * tcs), rb = __builtin_fmaf(a32, tsn, b32 * tcs);
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        dst[0] = (_Float16)ra;
+        dst[half] = (_Float16)rb;
+    }
+}
+
 // Waves per workgroup of the decode kernels, per kind of launch (0 q/k/v block, 1 short projection, 2 long rows / two rows per wave,
 // 3 everything else).  Every workgroup of these launches is resident at once, so a launch lasts as long as the CU with the most
 // workgroups: the counts below deal the 7B shapes evenly over 256 CUs where that measured faster (profiles/r03_run21_gemv_waves_per_block.md);
@@ -272,6 +490,17 @@ int pick_wpb(int kind) {
         forced[kind] = (v >= 1 && v <= 8) ? v : dflt[kind];
     }
     return forced[kind];
+}
+
+// SC_GEMV_GENERIC=1 pins the generic kernels (A/B runs); any SC_GEMV_WPB_* / SC_GEMV_RPW_FEW knob does the same (they tune the generic kernels)
+bool use_specialised() {
+    static const bool on = [] {
+        const char* g = getenv("SC_GEMV_GENERIC");
+        if (g && g[0] == '1') return false;
+        for (const char* n : {"SC_GEMV_WPB_0", "SC_GEMV_WPB_1", "SC_GEMV_WPB_2", "SC_GEMV_WPB_3", "SC_GEMV_RPW_FEW"}) if (getenv(n)) return false;
+        return true;
+    }();
+    return on;
 }
 
 }  // namespace
@@ -302,6 +531,13 @@ extern "C" int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void
     SC_REQUIRE(((reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(Wkv) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(rms_gamma)) & 15) == 0,
                "sc_decode_qkv_tab_f16: weights, x and gamma must be 16-byte aligned");
     const int ntask = (q_heads + 2 * kv_heads) * (Dh / 2);
+    if (K == 3584 && rms_gamma && use_specialised()) {              // the 7B shape: straight-line kernel (k_decode_qkv_u)
+        hipLaunchKernelGGL(k_decode_qkv_u<7>, dim3((unsigned)((ntask + 3) / 4)), dim3(256), (size_t)K * 2 + 16, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
+                           (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
+                           cache_ld, pos, q_heads, kv_heads, Dh, tab_q, tab_k, tab_rows);
+        SC_CHECK_LAUNCH("sc_decode_qkv_tab_f16");
+        return SC_OK;
+    }
     const int wpb = pick_wpb(0);
     hipLaunchKernelGGL(k_decode_qkv<true>, dim3((unsigned)((ntask + wpb - 1) / wpb)), dim3(64 * wpb), rms_gamma ? (size_t)K * 2 + 16 : 0, (hipStream_t)stream, (const _Float16*)Wq, (const _Float16*)Wkv,
                        (const _Float16*)bq, (const _Float16*)bkv, (const _Float16*)x, (const _Float16*)rms_gamma, rms_eps, (_Float16*)q_out, (_Float16*)cache,
@@ -325,6 +561,24 @@ extern "C" int sc_gemv_f16(const void* W, const void* x, const void* bias, const
     const size_t gsm = rms_gamma ? (size_t)K * 2 + 16 : 0;          // the normalised activation vector + 4 wave sums (block_rmsnorm_to_lds)
     SC_REQUIRE(gsm <= 65536, "sc_gemv_f16: fused RMSNorm needs K <= 32760");
     const bool few = N < 16384 && epilogue != SC_EPI_SWIGLU;
+    // the 7B shapes (K = 3584 = 7 slices, K = 18944 = 37 slices): straight-line kernels (k_gemv_u); everything else: the generic ones
+    if (!y_row && use_specialised() && (K == 3584 || (K == 18944 && few && !out_f32 && !rms_gamma))) {
+        const _Float16* gm = (const _Float16*)rms_gamma;
+        const size_t lds = (size_t)K * 2 + 16;
+#define SC_GU(SW, F32, RPW, NS, WPB, UNR)                                                                                                             \
+    do {                                                                                                                                              \
+        const dim3 g_((unsigned)((N + (WPB) * (RPW) - 1) / ((WPB) * (RPW)))), b_(64 * (WPB));                                                         \
+        if (gm) hipLaunchKernelGGL((k_gemv_u<SW, F32, true, RPW, NS, WPB, UNR>), g_, b_, lds, s, w, xx, b, r, y, N, gm, rms_eps);                      \
+        else hipLaunchKernelGGL((k_gemv_u<SW, F32, false, RPW, NS, WPB, UNR>), g_, b_, lds, s, w, xx, b, r, y, N, gm, rms_eps);                        \
+    } while (0)
+        if (K == 18944) hipLaunchKernelGGL((k_gemv_u<false, false, false, 2, 37, 7, 6>), dim3((unsigned)((N + 13) / 14)), dim3(448), lds, s, w, xx, b, r, y, N, gm, rms_eps);
+        else if (epilogue == SC_EPI_SWIGLU) SC_GU(true, false, 4, 7, 4, 2);
+        else if (out_f32) { if (few) SC_GU(false, true, 1, 7, 4, 7); else SC_GU(false, true, 4, 7, 4, 2); }
+        else { if (few) SC_GU(false, false, 1, 7, 4, 7); else SC_GU(false, false, 4, 7, 4, 2); }
+#undef SC_GU
+        SC_CHECK_LAUNCH("sc_gemv_f16");
+        return SC_OK;
+    }
     static int rpw_few = -1;                        // SC_GEMV_RPW_FEW=1|2|4: rows per wave of the small projections (A/B runs)
     if (rpw_few < 0) { const char* e = getenv("SC_GEMV_RPW_FEW"); const int v = e ? atoi(e) : 1; rpw_few = (v == 2 || v == 4) ? v : 1; }   // anything else -> 1
     // the tuning knob only applies where a kernel for that row count is instantiated (fp16 output); the fp32-output path of a short

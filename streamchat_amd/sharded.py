@@ -70,6 +70,7 @@ class ShardedMemory:
         self.next_node = 0
         self.row_shape = None       # (P, D), dtype, device of a feature row
         self._send = self._recv = None
+        self.traffic = dict(fetches=0, bytes_moved=0)        # row bytes that crossed ranks in fetch() (computed from the Refs: the same number on every rank)
         self.kmeans_max_iter = 10   # weighted_kmeans_feature's default (utiles.py:291): fixes how many reseed rows a merge draws
 
     # ---------------------------------------------------------------------------------------------
@@ -164,19 +165,30 @@ class ShardedMemory:
         _, kind, i, lo, hi = piece
         return self.store[(kind, i)][lo:hi]
 
-    def fetch(self, refs, dst=0, mode="allgather"):
+    def fetch(self, refs, dst=0, mode="gather"):
         """Rows of `refs` (in order) as ONE [rows, P, D] tensor on rank `dst` (None elsewhere).  `refs` must be identical on every
-        rank.  mode "allgather": one all_gather_into_tensor of max-rows-per-rank (the selected features of a question);
-        mode "p2p": owners send their pieces straight to dst (the merge group when it straddles ranks)."""
+        rank.
+        mode "gather" (default; "p2p" is the same path): gather-to-root - every owner sends exactly its pieces straight into their final
+        position of dst's [rows] buffer, as ONE batch of point-to-point transfers (RCCL: one group, each peer over its own xGMI link).
+        Only dst allocates, and only what it consumes: bytes moved = the rows dst lacks (reference inference_streaming_longva_v2.py:
+        696-699 hands the selected rows to ONE generate call).  Round 4 used the all-gather for the selected rows of a question: every
+        rank then held world x max-rows-per-rank rows although only rank 0 reads them (C4: 8 x 85 frames x 4.13 MB = 2.8 GB of buffers
+        and 7 x the traffic for 351 MB of payload).
+        mode "allgather": one all_gather_into_tensor of max-rows-per-rank slots - kept for a consumer on EVERY rank (none today)."""
         ctx = self.ctx
         pieces = [p for r in refs for p in r.pieces]
         if ctx.world == 1 and not self.always_collective:
             return U.cat_frames([self._local(p) for p in pieces])                    # adjacent bank rows: a view, no copy
         (P, D), dtype, dev = self.row_shape
         total = sum(p[4] - p[3] for p in pieces)
+        if mode == "gather" and ctx.world == 1:
+            mode = "allgather"            # (always_collective at world 1, the 1-rank RCCL test: there is no peer to send to; make the collective call)
         if all(p[0] == dst for p in pieces) and not (self.always_collective and mode == "allgather"):   # nothing to move (e.g. C4's first ten chunks)
             return U.cat_frames([self._local(p) for p in pieces]) if ctx.rank == dst else None
-        if mode == "p2p":
+        row_bytes = P * D * torch.empty((), dtype=dtype).element_size()
+        self.traffic["fetches"] += 1
+        if mode in ("gather", "p2p"):
+            self.traffic["bytes_moved"] += row_bytes * sum(p[4] - p[3] for p in pieces if p[0] != dst)      # (identical on every rank: from the Refs)
             sends, recvs, out, off = [], [], None, 0
             if ctx.rank == dst:
                 out = torch.empty((total, P, D), dtype=dtype, device=dev)
@@ -197,6 +209,7 @@ class ShardedMemory:
         for p in pieces:
             counts[p[0]] += p[4] - p[3]
         cap = max(counts)
+        self.traffic["bytes_moved"] += row_bytes * cap * ctx.world * (ctx.world - 1)            # every rank receives the other ranks' slots
         if self._send is None or self._send.shape[0] < cap:
             self._send = torch.empty((cap, P, D), dtype=dtype, device=dev)
             self._recv = torch.empty((ctx.world * cap, P, D), dtype=dtype, device=dev)

@@ -1,0 +1,45 @@
+"""Helper of test_gpu_gemv_spec.py: every decode projection of the Qwen2-7B shapes on seeded inputs -> an .npz of raw output bits.
+Run in a subprocess once with SC_GEMV_GENERIC=1 (the generic run-time-loop kernels of gemv.hip) and once without (the shape-specialised
+straight-line kernels): the two files must be bit-identical."""
+import sys
+import numpy as np
+import torch
+from streamchat_amd import ops
+
+
+def main(path):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rn = lambda *s, std=1.0: (torch.randn(*s, device="cuda", generator=g) * std).half()
+    out = {}
+    H, I, V = 3584, 18944, 152064
+    x, xm = rn(H), rn(I, std=0.5)
+    gamma, res, bias = 1 + rn(H, std=0.1), rn(H), rn(H, std=0.1)
+    cases = dict(o=(rn(H, H, std=0.02), x, None, res, "none", False, None),
+                 o_bias_norm=(rn(H, H, std=0.02), x, bias, res, "none", False, gamma),
+                 q_f32=(rn(H, H, std=0.02), x, bias, None, "none", True, gamma),
+                 kv_f32=(rn(1024, H, std=0.02), x, rn(1024, std=0.1), None, "none", True, gamma),
+                 down=(rn(H, I, std=0.02), xm, None, res, "none", False, None),
+                 gate_up=(rn(2 * 4096, H, std=0.02), x, None, None, "swiglu", False, gamma),
+                 gate_up_nonorm=(rn(2 * 4096, H, std=0.02), x, None, None, "swiglu", False, None),
+                 head=(rn(16384 + 48, H, std=0.02), x, None, None, "none", True, gamma),          # N % 16 != 0: the clamped last workgroup
+                 wide_f16=(rn(16384, H, std=0.02), x, bias.repeat(5)[:16384].contiguous(), None, "none", False, None),
+                 ragged_rows=(rn(H - 3, H, std=0.02), x, None, res[: H - 3].contiguous(), "none", False, None))
+    for name, (w, xv, b, r, epi, f32, gm) in cases.items():
+        y = ops.gemv(w, xv, b, residual=r, epilogue=epi, out_f32=f32, rms_gamma=gm, rms_eps=1e-6)
+        out[name] = y.cpu().numpy().view(np.uint32 if f32 else np.uint16)
+    # the fused q/k/v launch of the captured decode graph, three positions
+    Hq, Hkv, Dh = 28, 4, 128
+    wq, wkv, bq, bkv = rn(Hq * Dh, H, std=0.02), rn(2 * Hkv * Dh, H, std=0.02), rn(Hq * Dh, std=0.1), rn(2 * Hkv * Dh, std=0.1)
+    tq, tk = ops.rope_table(4096, Dh, 1e6, Dh ** -0.5 * ops.LOG2E, "cuda"), ops.rope_table(4096, Dh, 1e6, 1.0, "cuda")
+    cache = torch.zeros(4096, 2 * Hkv * Dh, dtype=torch.float16, device="cuda")
+    for p in (0, 1, 3001):
+        q = torch.empty(Hq * Dh, dtype=torch.float16, device="cuda")
+        ops.decode_qkv_tab(wq, wkv, bq, bkv, x, gamma, 1e-6, q, cache, torch.tensor([p], dtype=torch.int32, device="cuda"), Hq, Hkv, Dh, tq, tk)
+        out[f"qkv_q_{p}"] = q.cpu().numpy().view(np.uint16)
+        out[f"qkv_row_{p}"] = cache[p].cpu().numpy().view(np.uint16)
+    torch.cuda.synchronize()
+    np.savez(path, **out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -42,13 +42,21 @@ def _worker(rank, world, port, q):
     refs = [mem.frame_ref(0, f, f + 1) for f in wanted_frames] + [mem.frame_ref(0, 70, 130)]        # the last one straddles both ranks
     refs = mem.broadcast_refs(refs if rank == 0 else None)
     expect = [float(f) for f in wanted_frames] + [float(f) for f in range(70, 130)]
-    for mode in ("allgather", "p2p"):
+    row_bytes, moved = P * Dm * 4, {}
+    for mode in ("allgather", "p2p", "gather"):
         for dst in (0, 1):
+            before = mem.traffic["bytes_moved"]
             got = mem.fetch(refs, dst=dst, mode=mode)
+            moved[(mode, dst)] = mem.traffic["bytes_moved"] - before
             if rank == dst:
                 ok = ok and got.shape == (len(expect), P, Dm) and got[:, 0, 0].tolist() == expect and bool((got == got[:, :1, :1]).all())
             else:
                 ok = ok and got is None
+    # gather-to-root moves exactly the rows dst lacks (for dst 0: the frames rank 1 owns, i.e. >= parts[1][0], incl. the tail of the
+    # straddling ref); the all-gather moves world x cap slots to every rank
+    lacks0 = sum(1 for f in expect if f >= parts[1][0])
+    ok = ok and moved[("gather", 0)] == lacks0 * row_bytes and moved[("gather", 1)] == (len(expect) - lacks0) * row_bytes
+    ok = ok and moved[("p2p", 0)] == moved[("gather", 0)] and moved[("allgather", 0)] == max(lacks0, len(expect) - lacks0) * 2 * row_bytes
     only0 = mem.fetch([mem.frame_ref(0, 0, 80)], dst=0)                    # rows already on dst: no collective, a view of the bank
     ok = ok and ((only0.data_ptr() == bank.data_ptr()) if rank == 0 else only0 is None)
     ok = ok and D.broadcast_object(ctx, "summary" if rank == 1 else None, src=1) == "summary"
