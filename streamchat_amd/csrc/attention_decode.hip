@@ -97,16 +97,24 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
 // in the layout k_attn_combine reads.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DCH = 32;                            // kv rows per chunk
+#ifndef SC_DEC_ABL
+#define SC_DEC_ABL 0
+#endif
 #ifndef SC_DEC_PD
 #define SC_DEC_PD 2                                // chunks in flight per wave = stages of the K and of the V ring
 #endif
-constexpr int DEC_PD = SC_DEC_PD;
+#ifndef SC_DEC_NW
+#define SC_DEC_NW 4                                // streaming waves per workgroup (a power of two)
+#endif
+constexpr int DEC_PD = SC_DEC_PD, DEC_NW = SC_DEC_NW, DEC_NW_LOG = DEC_NW == 8 ? 3 : (DEC_NW == 4 ? 2 : (DEC_NW == 2 ? 1 : 0));
 static_assert(DEC_PD >= 1 && 16 * DEC_PD - 8 < 64, "vmcnt is a 6-bit counter");
+static_assert((1 << DEC_NW_LOG) == DEC_NW, "1, 2, 4 or 8 waves");
 
 template <int DH>
-__global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
+__global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                                         const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
-                                                        const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs) {
+                                                        const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs,
+                                                        int group) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(DH == 128, "the K ring is laid out for 256-byte rows");
     constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one K or V chunk (8 KiB at Dh = 128)
@@ -115,14 +123,25 @@ __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rl = lane & 15, g = lane >> 4;
-    const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit, h = bh % Hq, b = bh / Hq;
-    const int hk = h / (Hq / Hkv);
+    // grid = (split, head, batch): no integer division in the prologue (round 4 decoded a flat block index with three of them, ~60
+    // scalar instructions in front of the first memory request of a 22 us kernel)
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int hk = group == 1 ? h : h / group;                                          // group = Hq / Hkv (1 when the caller packs the G heads as query rows)
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
-    // chunks of this split, then of this wave
-    const int nch = (kv_valid + DCH - 1) / DCH, cps = (nch + nsplit - 1) / nsplit;
+    // chunks of this split, then of this wave: EVEN shares (sizes differ by at most one chunk).  Round 4 cut ceil(nch / nsplit) chunks per
+    // split and ceil(that / 4) per wave: at 49 153 keys (1537 chunks, 64 splits) that is 25 chunks for 61 workgroups, 12 for one and none
+    // for two, and 7 | 7 | 7 | 4 inside a workgroup - the launch lasted 7 chunk times where 6.004 would do
+#ifdef SC_DEC_OLD_PARTITION
+    const int cps = ((kv_valid + DCH - 1) / DCH + nsplit - 1) / nsplit, nch = (kv_valid + DCH - 1) / DCH;
     const int s_lo = min(split * cps, nch), s_hi = min(s_lo + cps, nch);
-    const int cpw = (s_hi - s_lo + 3) >> 2;
+    const int cpw = (s_hi - s_lo + DEC_NW - 1) >> DEC_NW_LOG;
     const int c_lo = min(s_lo + wave * cpw, s_hi), c_hi = min(c_lo + cpw, s_hi);
+#else
+    const int nch = (kv_valid + DCH - 1) / DCH;
+    const int cq = nch / nsplit, cr = nch - cq * nsplit;                                // the first cr splits take cq + 1 chunks
+    const int s_lo = split * cq + min(split, cr), ns = cq + (split < cr ? 1 : 0);
+    const int c_lo = s_lo + ((ns * wave) >> DEC_NW_LOG), c_hi = s_lo + ((ns * (wave + 1)) >> DEC_NW_LOG);
+#endif
     const int row_end = min(c_hi * DCH, kv_valid);                                      // rows of this wave: [c_lo * 32, row_end)
 
     // Q fragments (B operand: column = query row rl, k-slots = 8 head-dim elements): inline asm, so that no compiler-tracked vector
@@ -187,6 +206,13 @@ __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restri
         for (int u = 0; u < DEC_PD; ++u) { issue_k(c_lo + u); issue_v(c_lo + u); }          // (past c_hi: zero extent -> no traffic)
         for (int c = c_lo; c < c_hi; ++c) {
             const unsigned stage = (unsigned)((c % DEC_PD) * CHB);
+#if SC_DEC_ABL == 1                 // ablation: the stream alone (waits + re-issue, no LDS reads, no arithmetic)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+            issue_k(c + DEC_PD);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+            issue_v(c + DEC_PD);
+            continue;
+#endif
             // ---- S^T = K . Q^T for the 32 rows ----
             static_assert(DS == 4, "the fences below name 8 K fragments and 4 q fragments");
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : "n"(CNT) : "memory");
@@ -266,21 +292,23 @@ __global__ __launch_bounds__(256, 1) void k_attn_decode(const _Float16* __restri
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();
-    float* mo = reinterpret_cast<float*>(smem);             // [4][DH][16] O^T, then [4][16] m, [4][16] l
-    float* mm = mo + 4 * DH * 16;
-    float* ml = mm + 64;
+    float* mo = reinterpret_cast<float*>(smem);             // [NW][DH][16] O^T, then [NW][16] m, [NW][16] l
+    float* mm = mo + DEC_NW * DH * 16;
+    float* ml = mm + DEC_NW * 16;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mo[(wave * DH + db * 16 + g * 4 + r) * 16 + rl] = o[db][r];
     if (g == 0) { mm[wave * 16 + rl] = m_run; ml[wave * 16 + rl] = l_run; }
     __syncthreads();
-    for (int e = tid; e < Sq * DH; e += 256) {
+    for (int e = tid; e < Sq * DH; e += 64 * DEC_NW) {
         const int q = e / DH, d = e - q * DH;
-        float M = fmaxf(fmaxf(mm[q], mm[16 + q]), fmaxf(mm[32 + q], mm[48 + q]));
+        float M = mm[q];
+#pragma unroll
+        for (int w = 1; w < DEC_NW; ++w) M = fmaxf(M, mm[w * 16 + q]);
         float acc = 0.f, l = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < DEC_NW; ++w) {
             const float mw = mm[w * 16 + q];
             const float wt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
             acc += mo[(w * DH + d) * 16 + q] * wt;
@@ -304,11 +332,12 @@ void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B
 
 void sc_attn_decode_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
                            const int32_t* kv_len, float* part, int nsplit, int q_hs, long q_bs, hipStream_t s) {
-    constexpr int LDS_DEC = 4 * 2 * DEC_PD * DCH * 128 * 2;          // 4 waves x (K ring + V ring) x DEC_PD stages of 8 KiB
+    constexpr int LDS_RING = DEC_NW * 2 * DEC_PD * DCH * 128 * 2, LDS_MERGE = DEC_NW * (128 * 16 + 32) * 4;   // NW waves x (K ring + V ring) x DEC_PD stages of 8 KiB
+    constexpr int LDS_DEC = LDS_RING > LDS_MERGE ? LDS_RING : LDS_MERGE;
     static bool attr_done[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
-    hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)(B * Hq * nsplit)), dim3(256), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
-                       (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs);
+    hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)nsplit, (unsigned)Hq, (unsigned)B), dim3(64 * DEC_NW), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
+                       (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs, Hq / Hkv);
 }

@@ -1061,6 +1061,209 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const _Float16* __restrict_
     }
 }
 
+// Round 5: k_gemm_skinny for K known at compile time (the Qwen2-7B widths 3584 and 18944): the K-quarter of a wave is straight-line
+// code in batches of BT k-steps with two register buffers.  In the run-time loop above hipcc requests the activation fragments BEHIND
+// the weights they multiply (vmcnt retires in order: the first MFMA of a batch waits for the whole batch and then for an L2 round
+// trip), consumes a batch before it requests the next one, and peels the trip % 8 remainder into one-k-step trips - the batched
+// caption decode (26 sequences) ran its projections at 1.7 - 2.5 TB/s (profiles/r05_*).  Here the queue of a wave is
+//   [x fragments of batch 0] [W of batch 0] | per batch b: [x of b + 1] [W of b + 1]  ->  MFMAs of batch b
+// (x first: it comes out of L2 and is back long before the weights), same k order per accumulator as the loop above: the sums are
+// bit-identical to k_gemm_skinny's.
+template <int EPI, bool OUT_F32, int MG, int KW, int BT>      // KW = k-steps (of 32) per wave = K / 4 / 32
+__global__ __launch_bounds__(256) void k_gemm_skinny_u(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                       const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                       void* __restrict__ Cout, int ldc, int M, int N) {
+    constexpr int K = KW * 32 * 4, NB = (KW + BT - 1) / BT;
+    __shared__ float red[3][MG][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rl = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int k_lo = wave * (K / 4);
+    const _Float16* wp = W + (size_t)(n0 + rl) * (size_t)K + k_lo + g * 8;
+    const _Float16* xp[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        int m = mg * 16 + rl;
+        m = m < M ? m : M - 1;
+        xp[mg] = A + (size_t)m * (size_t)lda + k_lo + g * 8;
+    }
+    sc_f4 acc[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    sc_h8 wf[2][BT], xf[2][BT][MG];
+    auto load = [&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+#pragma unroll
+        for (int u = 0; u < BT; ++u)
+            if (B * BT + u < KW) {
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) xf[B & 1][u][mg] = *reinterpret_cast<const sc_h8*>(xp[mg] + (B * BT + u) * 32);
+            }
+#pragma unroll
+        for (int u = 0; u < BT; ++u)
+            if (B * BT + u < KW) wf[B & 1][u] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp + (B * BT + u) * 32));
+    };
+    auto run = [&](auto self, auto bc) -> void {
+        constexpr int B = decltype(bc)::value;
+        if constexpr (B < NB) {
+            if constexpr (B + 1 < NB) load(std::integral_constant<int, B + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BT; ++u)
+                if (B * BT + u < KW) {
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[B & 1][u], xf[B & 1][u][mg], acc[mg], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            self(self, std::integral_constant<int, B + 1>{});
+        }
+    };
+    load(std::integral_constant<int, 0>{});
+    run(run, std::integral_constant<int, 0>{});
+    if (wave > 0) {
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][mg][r][lane] = acc[mg][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int n = n0 + g * 4;
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mg][r] + red[0][mg][r][lane] + red[1][mg][r][lane] + red[2][mg][r][lane] + (bias ? (float)bias[n + r] : 0.f);
+        const int m = mg * 16 + rl;
+        if (m >= M) continue;
+        if (EPI == SC_EPI_SWIGLU) {
+            const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[2], o1 = v[1] / (1.0f + __expf(-v[1])) * v[3];
+            const sc_h2 o = {(_Float16)o0, (_Float16)o1};
+            *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = epi_apply(v[r], EPI);
+            if (R) { const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(R + (size_t)m * (size_t)ldr + n); for (int r = 0; r < 4; ++r) v[r] += (float)r4[r]; }
+            if (OUT_F32) *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+            else *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+}
+
+// Round 5: the batched-decode projection for K = 3584 (Qwen2-7B hidden width) with the ACTIVATIONS RESIDENT IN REGISTERS.
+// k_gemm_skinny(_u) re-reads the M x K activation block from L2 for every strip of 16 weight rows: at 26 rows that is twice the bytes of
+// the weights themselves through the texture path (gate/up: 543 MB of x for 271 MB of W), and the weight stream stood at 2.3 - 2.9
+// TB/s.  Here a workgroup is persistent over a contiguous range of strips (even shares of N / 16 over the CUs); wave w keeps the
+// MFMA B fragments of x[:, w * 896 : (w + 1) * 896] - 28 k-steps x MG fragments = 224 VGPRs at MG = 2, one wave per SIMD owns the
+// whole 512-register file - for its lifetime, and per strip streams ONLY weights: 28 x 16 B per lane, all requested at once, two
+// register buffers so that strip s + 1 is in flight while strip s is multiplied and reduced (4 waves = 4 K-quarters, partial tiles
+// through a double-buffered LDS scratch, one barrier per strip; wave 0 applies the epilogue).  Everything a strip's epilogue reads
+// (bias, residual) is requested BEFORE the next strip's weights, so that no wait ever drains the weight queue.  Same k order per
+// accumulator and same cross-wave sum as k_gemm_skinny: bit-identical results.
+template <int EPI, bool OUT_F32, int MG>
+__global__ __launch_bounds__(256) void k_gemm_skinny_x(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                       const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                       void* __restrict__ Cout, int ldc, int M, int N, int strips_q, int strips_r) {
+    constexpr int KW = 28, K = KW * 32 * 4;
+    __shared__ float red[2][3][MG][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rl = lane & 15, g = lane >> 4;
+    const int k_lo = wave * (K / 4);
+    const int b = blockIdx.x;
+    const int s_lo = b * strips_q + min(b, strips_r), s_hi = s_lo + strips_q + (b < strips_r ? 1 : 0);      // the first strips_r workgroups take one strip more
+    if (s_lo >= s_hi) return;
+    sc_h8 xf[KW][MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        int m = mg * 16 + rl;
+        m = m < M ? m : M - 1;
+        const _Float16* xp = A + (size_t)m * (size_t)lda + k_lo + g * 8;
+#pragma unroll
+        for (int u = 0; u < KW; ++u) xf[u][mg] = *reinterpret_cast<const sc_h8*>(xp + u * 32);
+    }
+    const _Float16* wbase = W + (size_t)rl * (size_t)K + k_lo + g * 8;
+    sc_h8 wa[KW], wb[KW];
+    sc_h4 ba, bb, ra[MG], rb[MG];
+    auto load_w = [&](sc_h8 (&buf)[KW], int strip) {
+        const _Float16* wp = wbase + (size_t)strip * (size_t)(16 * K);
+#pragma unroll
+        for (int u = 0; u < KW; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const sc_h8*>(wp + u * 32));
+    };
+    auto load_e = [&](sc_h4& bv, sc_h4 (&rv)[MG], int strip) {          // what the epilogue of `strip` adds (null pointers read W / A: dropped)
+        const int n = strip * 16 + g * 4;
+        bv = *reinterpret_cast<const sc_h4*>(bias ? bias + n : W);
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            int m = mg * 16 + rl;
+            m = m < M ? m : M - 1;
+            rv[mg] = *reinterpret_cast<const sc_h4*>(R ? R + (size_t)m * (size_t)ldr + n : A);
+        }
+    };
+    auto compute = [&](const sc_h8 (&buf)[KW], const sc_h4& bv, const sc_h4 (&rv)[MG], int strip) {
+        sc_f4 acc[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KW; ++u)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(buf[u], xf[u][mg], acc[mg], 0, 0, 0);
+        float (*rd)[MG][4][64] = red[strip & 1];
+        if (wave > 0) {
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rd[wave - 1][mg][r][lane] = acc[mg][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        const int n = strip * 16 + g * 4;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mg][r] + rd[0][mg][r][lane] + rd[1][mg][r][lane] + rd[2][mg][r][lane] + (bias ? (float)bv[r] : 0.f);
+            const int m = mg * 16 + rl;
+            if (m >= M) continue;
+            if (EPI == SC_EPI_SWIGLU) {
+                const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[2], o1 = v[1] / (1.0f + __expf(-v[1])) * v[3];
+                const sc_h2 o = {(_Float16)o0, (_Float16)o1};
+                *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = epi_apply(v[r], EPI);
+                if (R) { for (int r = 0; r < 4; ++r) v[r] += (float)rv[mg][r]; }
+                if (OUT_F32) *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+                else *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+    };
+    int st = s_lo;
+    load_e(ba, ra, st);
+    load_w(wa, st);
+    while (st + 2 < s_hi) {                // strips st and st + 1 are processed in this trip; st + 2 exists: no load sits behind a condition
+        // (the scheduling fences keep the next strip's loads AHEAD of this strip's MFMAs: left alone, hipcc sinks them below the MFMAs to
+        //  reuse the registers they free - one buffer instead of two, and every strip starts with a full memory round trip)
+        load_e(bb, rb, st + 1); load_w(wb, st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(wa, ba, ra, st);
+        __builtin_amdgcn_sched_barrier(0);
+        load_e(ba, ra, st + 2); load_w(wa, st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(wb, bb, rb, st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        st += 2;
+    }
+    if (st + 1 < s_hi) {
+        load_e(bb, rb, st + 1); load_w(wb, st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(wa, ba, ra, st);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(wb, bb, rb, st + 1);
+    } else {
+        compute(wa, ba, ra, st);
+    }
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
@@ -1073,6 +1276,37 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
     if (force == 0 && M <= 32 && K % 128 == 0 && a_grp == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0)) {      // few rows: stream W once
         const dim3 grid((unsigned)(N / 16)), block(256);
+        static int unrolled = -1;                 // SC_SKINNY_GENERIC=1 pins the run-time-loop kernel (A/B runs, bit-identity test)
+        if (unrolled < 0) { const char* e = getenv("SC_SKINNY_GENERIC"); unrolled = (e && e[0] == '1') ? 0 : 1; }
+        if constexpr (EPI == SC_EPI_NONE || EPI == SC_EPI_SWIGLU) if (unrolled && (K == 3584 || K == 18944)) {
+#define SC_LSU(F32, MGV, KWV, BTV) hipLaunchKernelGGL((k_gemm_skinny_u<EPI, F32, MGV, KWV, BTV>), grid, block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
+                                                      (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N)
+            static int xres = -1;                     // SC_SKINNY_XREG=0: the x-from-L2 kernel for K = 3584 too (A/B runs)
+            if (xres < 0) { const char* e = getenv("SC_SKINNY_XREG"); xres = (e && e[0] == '0') ? 0 : 1; }
+            static int n_cu_x[16] = {};
+            if (n_cu_x[dev] == 0) { int n = 0; n_cu_x[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+            // activations resident in registers, persistent over strips (k_gemm_skinny_x): where a workgroup gets at least two strips (gate/up,
+            // lm_head); with one strip per workgroup (the 3584-row projections) loading x first only delays the weights: k_gemm_skinny_u
+            if (K == 3584 && xres && N / 16 >= 2 * n_cu_x[dev]) {
+                const int strips = N / 16, gx = n_cu_x[dev];
+#define SC_LSX(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny_x<EPI, F32, MGV>), dim3((unsigned)gx), block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
+                                            (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, strips / gx, strips % gx)
+                if (M <= 16) { if (out_f32) SC_LSX(true, 1); else SC_LSX(false, 1); }
+                else { if (out_f32) SC_LSX(true, 2); else SC_LSX(false, 2); }
+#undef SC_LSX
+                SC_CHECK_LAUNCH("sc_gemm_f16");
+                return SC_OK;
+            }
+            // (one strip per workgroup and at most ~one workgroup per CU: the whole K-quarter of a wave in flight at once - 28 weight + 28 MG
+            //  activation fragments per lane)
+            if (K == 3584) { if (M <= 16) { if (out_f32) SC_LSU(true, 1, 28, 28); else SC_LSU(false, 1, 28, 28); }
+                             else { if (out_f32) SC_LSU(true, 2, 28, 7); else SC_LSU(false, 2, 28, 7); } }
+            else { if (M <= 16) { if (out_f32) SC_LSU(true, 1, 148, 8); else SC_LSU(false, 1, 148, 8); }
+                   else { if (out_f32) SC_LSU(true, 2, 148, 8); else SC_LSU(false, 2, 148, 8); } }
+#undef SC_LSU
+            SC_CHECK_LAUNCH("sc_gemm_f16");
+            return SC_OK;
+        }
 #define SC_LSK(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny<EPI, F32, MGV>), grid, block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
                                               (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K)
         if (M <= 16) { if (out_f32) SC_LSK(true, 1); else SC_LSK(false, 1); }

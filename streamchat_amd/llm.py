@@ -75,10 +75,13 @@ class Qwen2Model:
             g, u = take(p + "mlp.gate_proj.weight"), take(p + "mlp.up_proj.weight")
             wgu = torch.cat([g.view(I // 2, 2, H), u.view(I // 2, 2, H)], dim=1).reshape(2 * I, H).contiguous()   # (g g u u) interleave
             del g, u
+            # q | k | v projection weights in ONE buffer (round 5): wq and wkv are row views of it (every kernel that takes them separately
+            # is unchanged), and the batched decode step projects all three with one launch over `wqkv`
+            dq_ = cfg.heads * Dh
+            wqkv = torch.cat([take(p + "self_attn.q_proj.weight"), take(p + "self_attn.k_proj.weight"), take(p + "self_attn.v_proj.weight")]).contiguous()
+            bqkv = torch.cat([take(p + "self_attn.q_proj.bias"), take(p + "self_attn.k_proj.bias"), take(p + "self_attn.v_proj.bias")]).contiguous()
             self.L.append(dict(
-                wq=take(p + "self_attn.q_proj.weight"), bq=take(p + "self_attn.q_proj.bias"),
-                wkv=torch.cat([take(p + "self_attn.k_proj.weight"), take(p + "self_attn.v_proj.weight")]).contiguous(),
-                bkv=torch.cat([take(p + "self_attn.k_proj.bias"), take(p + "self_attn.v_proj.bias")]).contiguous(),
+                wqkv=wqkv, bqkv=bqkv, wq=wqkv[:dq_], bq=bqkv[:dq_], wkv=wqkv[dq_:], bkv=bqkv[dq_:],
                 wo=take(p + "self_attn.o_proj.weight"), wgu=wgu, wd=take(p + "mlp.down_proj.weight"),
                 ln1=take(p + "input_layernorm.weight"), ln2=take(p + "post_attention_layernorm.weight")))
         self.cache = None
@@ -462,14 +465,18 @@ class BatchDecoder:
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self._ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
         first_logits = []
-        saved = (lm.cache, lm.cache_len, lm.max_seq)
+        # (forward() also records the split-KV factor of "the prompt in the cache": it belongs to the saved state - ADVICE r04 - or an eager
+        #  decode that continues the earlier prompt would merge its partials in another grouping than a DecodeGraph built for it)
+        saved = (lm.cache, lm.cache_len, lm.max_seq, getattr(lm, "_nsplit_prompt", None))
         try:
             for b, e in enumerate(prompts):
                 lm.cache, lm.cache_len, lm.max_seq = [cl[b] for cl in self.cache], 0, self.cap
                 first_logits.append(lm.forward(e.to(dev)))
                 self.len[b] = lm.cache_len
         finally:
-            lm.cache, lm.cache_len, lm.max_seq = saved
+            lm.cache, lm.cache_len, lm.max_seq, lm._nsplit_prompt = saved
+        # fp32 q | k | v sums of one step: owned here (the decode step is graph-captured; the model's shared scratch may be regrown by a later call)
+        self._qkv32 = torch.empty((self.B, (c.heads + 2 * c.kv_heads) * c.head_dim), dtype=torch.float32, device=dev)
         self.logits = torch.stack(first_logits)                                  # [B, vocab] fp32
 
     def step(self, tokens):
@@ -484,7 +491,12 @@ class BatchDecoder:
             x = ops.rmsnorm(h, L["ln1"], c.eps)
             q = torch.empty((B, dq), dtype=torch.float16, device=h.device)
             kv = torch.empty((B, 2 * dkv), dtype=torch.float16, device=h.device)
-            lm._qkv_rows(x, L, 0, q, kv, positions=self.len)                    # fp32 sums -> RoPE at each sequence's position -> one rounding
+            # q | k | v in ONE projection launch over the fused weight (the same column sums as two launches), fp32 sums -> RoPE at each
+            # sequence's position -> one rounding (the numerics of Qwen2Model._qkv_rows)
+            s32 = ops.gemm(x, L["wqkv"], L["bqkv"], out=self._qkv32, out_f32=True)
+            tq, tk = self._rope_tabs
+            ops.rope_f32in(s32[:, :dq], tq, c.heads, Dh, q, 0, 0, self.len)
+            ops.rope_f32in(s32[:, dq:], tk, c.kv_heads, Dh, kv, dkv, 0, self.len)
             ck = self.cache[l]
             ck.view(B * self.cap, -1).index_copy_(0, rows, kv)
             # the G query heads of a KV group as G query ROWS of that KV head (addressing only; q batch stride = dq)
@@ -522,7 +534,11 @@ class BatchDecoder:
         sp = sampling if sampling is not None else Sampling(float(temperature) if do_sample and temperature > 0 else 0.0)
         eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else (set() if eos_token_id is None else {eos_token_id})   # HF allows a list
         longest = int(self.len.max().item()) + max_new_tokens
-        self.nsplit = max(1, min(64, ((longest + 63) // 64) // 4))
+        # split-KV factor of the batched step: ~10 workgroups per CU over the whole launch (B x KV heads x splits), at least ~24 chunks of 32
+        # rows per workgroup.  Round 4 took the batch-1 rule (64 splits): 6656 workgroups of < 3 chunks per wave at 26 x 22.7 k - the launch
+        # was its own prologue, merge and 64-partial combine (15.6 -> 11.5 ms per step at 24 splits, profiles/r05_*)
+        c_ = self.lm.cfg
+        self.nsplit = getattr(self, "nsplit_override", None) or max(1, min(64, ((longest + 31) // 32) // 24, -(-10 * 256 // (B * c_.kv_heads))))
         c = self.lm.cfg
         self._ws_attn = torch.empty(max(ops.attention_workspace_bytes(B, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
                                     dtype=torch.uint8, device=dev)

@@ -93,13 +93,12 @@ def compress_spatial_features(feature_list, compress_rate):
     B, SEQ, DIM = all_features.shape
     assert patch_size * patch_size == feature_list[0].shape[1], \
         f"For ViT feature map, {patch_size}*{patch_size}={patch_size**2} != {all_features.shape[1]}"
-    if all_features.is_cuda and all_features.dtype == torch.float16 and DIM % 8 == 0:        # device path: one HIP kernel (sc_avgpool_tokens_f16)
-        from . import ops
-        return list(torch.split(ops.avgpool_tokens(all_features, compress_rate), 1))
-    g = patch_size // compress_rate
-    x = all_features.reshape(B, patch_size, patch_size, DIM)[:, : g * compress_rate, : g * compress_rate]
-    x = x.reshape(B, g, compress_rate, g, compress_rate, DIM).float().mean(dim=(2, 4)).to(all_features.dtype)
-    return list(torch.split(x.reshape(B, -1, DIM), 1))
+    # one HIP kernel (sc_avgpool_tokens_f16: fp32 mean of the r x r window, one rounding); like every other op of the package there is no
+    # CPU / PyTorch path - ops.avgpool_tokens refuses anything but CUDA fp16 (round 4 still carried a torch `.float().mean()` fallback here)
+    from . import ops
+    if all_features.dtype != torch.float16 or DIM % 8 != 0:
+        raise ops.StreamChatHipError(f"compress_spatial_features: fp16 features with a width that is a multiple of 8 only (got {all_features.dtype}, {DIM})")
+    return list(torch.split(ops.avgpool_tokens(all_features, compress_rate), 1))
 
 
 # ------------------------------------------------------------------------------------------------

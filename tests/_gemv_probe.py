@@ -37,6 +37,15 @@ def main(path):
         ops.decode_qkv_tab(wq, wkv, bq, bkv, x, gamma, 1e-6, q, cache, torch.tensor([p], dtype=torch.int32, device="cuda"), Hq, Hkv, Dh, tq, tk)
         out[f"qkv_q_{p}"] = q.cpu().numpy().view(np.uint16)
         out[f"qkv_row_{p}"] = cache[p].cpu().numpy().view(np.uint16)
+    # batched decode projections (M <= 32 rows: k_gemm_skinny / k_gemm_skinny_u), 26 caption sequences and 8
+    for M in (26, 8):
+        xb, xmb = rn(M, H), rn(M, I, std=0.5)
+        resb = rn(M, H)
+        for name, (w, a, b, r, epi, f32) in dict(
+                q=(cases["q_f32"][0], xb, bias, None, "none", True), o=(cases["o"][0], xb, None, resb, "none", False),
+                gate_up=(cases["gate_up"][0], xb, None, None, "swiglu", False), down=(cases["down"][0], xmb, None, resb, "none", False)).items():
+            y = ops.gemm(a, w, b, residual=r, epilogue=epi, out_f32=f32)
+            out[f"gemm{M}_{name}"] = y.cpu().numpy().view(np.uint32 if f32 else np.uint16)
     torch.cuda.synchronize()
     np.savez(path, **out)
 

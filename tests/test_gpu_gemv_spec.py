@@ -15,16 +15,16 @@ pytestmark = pytest.mark.gpu
 def _run(tmp, generic):
     out = os.path.join(tmp, f"gemv_{'generic' if generic else 'spec'}.npz")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    env.pop("SC_GEMV_GENERIC", None)
+    env.pop("SC_GEMV_GENERIC", None); env.pop("SC_SKINNY_GENERIC", None)
     if generic:
-        env["SC_GEMV_GENERIC"] = "1"
+        env["SC_GEMV_GENERIC"] = env["SC_SKINNY_GENERIC"] = "1"
     subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gemv_probe.py"), out], check=True, env=env, cwd=ROOT, timeout=600)
     return np.load(out)
 
 
 def test_specialised_equals_generic_bitwise(tmp_path):
     a, b = _run(str(tmp_path), True), _run(str(tmp_path), False)
-    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 16
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 24
     for k in a.files:
         assert np.array_equal(a[k], b[k]), f"{k}: specialised kernel differs from the generic one in {int((a[k] != b[k]).sum())} of {a[k].size} outputs"
 

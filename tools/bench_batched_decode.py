@@ -12,6 +12,7 @@ ap.add_argument("--chunks", type=int, default=26)
 ap.add_argument("--ctx", type=int, default=22740)
 ap.add_argument("--new", type=int, default=48)
 ap.add_argument("--eager", action="store_true")
+ap.add_argument("--nsplit", type=int, nargs="*", default=[0])
 a = ap.parse_args()
 cfg = LM.Qwen2ConfigLite(**LM.QWEN2_7B)
 lm = LM.Qwen2Model(LM.random_qwen2_state_dict(cfg, seed=0), cfg, max_seq=4096, consume=True)
@@ -22,14 +23,17 @@ for c in dec.cache:
     c.normal_(0, 0.5)
 dec.len.fill_(a.ctx)
 torch.cuda.synchronize()
-dec.generate(8, use_graph=not a.eager)                     # warm-up (captures a graph of its own)
-dec.len.fill_(a.ctx)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-dec.generate(a.new, use_graph=not a.eager)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-steps = a.new - 1
-w_bytes = sum(t.numel() * 2 for L in lm.L for t in (L["wq"], L["wkv"], L["wo"], L["wgu"], L["wd"])) + lm.lm_head.numel() * 2
-kv_bytes = a.chunks * (a.ctx + a.new / 2) * 2 * cfg.kv_heads * cfg.head_dim * 2 * cfg.layers
-print(json.dumps(dict(chunks=a.chunks, ctx=a.ctx, steps=steps, ms_per_step=round(1e3 * dt / steps, 3), tok_per_s=round(a.chunks * steps / dt, 1),
-                      GB_per_step=round((w_bytes + kv_bytes) / 1e9, 2), TBps=round((w_bytes + kv_bytes) / (dt / steps) / 1e12, 3),
-                      frac_of_8TBps=round((w_bytes + kv_bytes) / (dt / steps) / 8e12, 3), nsplit=dec.nsplit)))
+for ns in a.nsplit:
+    dec.nsplit_override = ns or None
+    dec.len.fill_(a.ctx)
+    dec.generate(8, use_graph=not a.eager)                     # warm-up (captures a graph of its own)
+    dec.len.fill_(a.ctx)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    dec.generate(a.new, use_graph=not a.eager)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    steps = a.new - 1
+    w_bytes = sum(t.numel() * 2 for L in lm.L for t in (L["wq"], L["wkv"], L["wo"], L["wgu"], L["wd"])) + lm.lm_head.numel() * 2
+    kv_bytes = a.chunks * (a.ctx + a.new / 2) * 2 * cfg.kv_heads * cfg.head_dim * 2 * cfg.layers
+    print(json.dumps(dict(chunks=a.chunks, ctx=a.ctx, steps=steps, ms_per_step=round(1e3 * dt / steps, 3), tok_per_s=round(a.chunks * steps / dt, 1),
+                          GB_per_step=round((w_bytes + kv_bytes) / 1e9, 2), TBps=round((w_bytes + kv_bytes) / (dt / steps) / 1e12, 3),
+                          frac_of_8TBps=round((w_bytes + kv_bytes) / (dt / steps) / 8e12, 3), nsplit=dec.nsplit)))
