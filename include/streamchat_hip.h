@@ -49,11 +49,25 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *   4  round 4: the three consumers of a rotary table take the table's ROW COUNT (sc_gemm_headed_f16 `rope_tab_rows`, sc_rope_f32in_f16 and
  *      sc_decode_qkv_tab_f16 `tab_rows`): positions known on the host (pos0 + rows) beyond the table are SC_ERR_ARG, positions read from
  *      device memory (`positions[]`, `pos[0]`) are clamped to the last table row instead of reading past the allocation
+ *   5  round 5: + sc_build_info; + sc_stream_create_masked / sc_stream_destroy / sc_set_cu_budget (CU-partitioned streams: the HBM-bound
+ *      answer decode beside the MFMA-bound encode / prefill of the next segment); sc_attention_f16 decode path: grid and chunk shares
+ *      changed (results of a split-KV call differ in the last bit from version 4's, every caller sees one consistent kernel)
  */
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 
 int sc_abi_version(void);
 const char* sc_last_error(void);
+/* v5: how the library was built ("abi=5 attention=iterative-ilp decode=kernarg-preload"; "...(FALLBACK)" when the Makefile had to fall
+ * back to the default machine scheduler for attention.hip): performance numbers of different builds are not comparable - bench.py prints it */
+const char* sc_build_info(void);
+/* v5: CU-partitioned streams (hipExtStreamCreateWithCUMask).  A stream restricted to CUs [cu_first, cu_first + cu_count) of the device's CU
+ * mask (consecutive mask bits go round-robin over the 8 XCDs: use multiples of 8).  sc_set_cu_budget(n) makes the library's persistent
+ * launches (one workgroup per CU) size their grids for n CUs instead of the whole device (0 = whole device); it is process-wide: set it around
+ * the launches that go to a masked stream.  The reference has no such notion; it runs reader / updater / QA as Python threads on one default
+ * stream (reference previous_version/streaming_demo_llava_next_3.py:967-991). */
+int sc_stream_create_masked(int cu_first, int cu_count, int high_priority, sc_stream_t* out);
+int sc_stream_destroy(sc_stream_t stream);
+int sc_set_cu_budget(int n_cu);
 /* host out-params: number of CUs, 1 if the device is gfx950, total HBM bytes */
 int sc_device_info(int* cu_count, int* is_gfx950, size_t* hbm_bytes);
 

@@ -473,6 +473,15 @@ static bool attn_decode_enabled() {
     return on;
 }
 
+// which machine scheduler attention.hip was built with (Makefile: iterative-ilp, or the default one if that compile failed) - sc_build_info()
+const char* sc_attn_build_tag() {
+#ifdef SC_ATTN_SCHED_FALLBACK
+    return "attention=default-sched(FALLBACK)";
+#else
+    return "attention=iterative-ilp";
+#endif
+}
+
 extern "C" int sc_attention_variant(int Dh, int Sq, int nsplit) {
     if (Dh == 128 && nsplit == 1 && Sq >= 2048) return 1;
     if (Dh == 128 && nsplit > 1 && Sq <= 16 && attn_decode_enabled()) return 3;      // (non-causal calls; a causal call of this shape runs k_attn)

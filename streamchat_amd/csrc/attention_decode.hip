@@ -4,6 +4,7 @@
 // which costs these HBM-bound kernels 0.6-2 % (profiles/r03_run49_51_attn_sched_strategy.md): this file takes the default scheduler.
 #include "sc_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -100,23 +101,22 @@ constexpr int DCH = 32;                            // kv rows per chunk
 #ifndef SC_DEC_ABL
 #define SC_DEC_ABL 0
 #endif
-#ifndef SC_DEC_PD
-#define SC_DEC_PD 2                                // chunks in flight per wave = stages of the K and of the V ring
-#endif
 #ifndef SC_DEC_NW
 #define SC_DEC_NW 4                                // streaming waves per workgroup (a power of two)
 #endif
-constexpr int DEC_PD = SC_DEC_PD, DEC_NW = SC_DEC_NW, DEC_NW_LOG = DEC_NW == 8 ? 3 : (DEC_NW == 4 ? 2 : (DEC_NW == 2 ? 1 : 0));
-static_assert(DEC_PD >= 1 && 16 * DEC_PD - 8 < 64, "vmcnt is a 6-bit counter");
+constexpr int DEC_NW = SC_DEC_NW, DEC_NW_LOG = DEC_NW == 8 ? 3 : (DEC_NW == 4 ? 2 : (DEC_NW == 2 ? 1 : 0));
 static_assert((1 << DEC_NW_LOG) == DEC_NW, "1, 2, 4 or 8 waves");
 
-template <int DH>
+// DEC_PD = chunks in flight per wave = stages of the K and of the V ring: 2 (128 KiB of LDS, one workgroup per CU) or 1 (64 KiB, two
+// workgroups per CU: twice the waves, half the run-ahead each)
+template <int DH, int DEC_PD>
 __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __restrict__ Q, int ldq, const _Float16* __restrict__ Kp, int ldk,
                                                         const _Float16* __restrict__ Vp, int ldv, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
                                                         const int* __restrict__ kv_len, float* __restrict__ part, int nsplit, int q_hs, long q_bs,
                                                         int group) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(DH == 128, "the K ring is laid out for 256-byte rows");
+    static_assert(DEC_PD >= 1 && 16 * DEC_PD - 8 < 64, "vmcnt is a 6-bit counter");
     constexpr int DS = DH / 32, DB = DH / 16, VROW = DH * 2, CHB = DCH * VROW;          // bytes of one K or V chunk (8 KiB at Dh = 128)
     constexpr int WAVE_LDS = 2 * DEC_PD * CHB;                                          // [K stages | V stages] of one wave
     constexpr int CNT = 16 * DEC_PD - 8;                                                // vm ops younger than the chunk part being waited for (see the loop)
@@ -322,6 +322,14 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
 
 }  // namespace
 
+const char* sc_decode_build_tag() {
+#ifdef SC_KERNARG_PRELOAD
+    return "decode=kernarg-preload";
+#else
+    return "decode=plain";
+#endif
+}
+
 // launchers used by attention.hip
 void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B, int Sq, int Hq, int nsplit, int o_hs, long o_bs, hipStream_t s) {
     const dim3 grid((unsigned)(B * Hq * Sq));
@@ -332,12 +340,22 @@ void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B
 
 void sc_attn_decode_launch(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Sq, int Skv, int Hq, int Hkv, float scale_log2,
                            const int32_t* kv_len, float* part, int nsplit, int q_hs, long q_bs, hipStream_t s) {
-    constexpr int LDS_RING = DEC_NW * 2 * DEC_PD * DCH * 128 * 2, LDS_MERGE = DEC_NW * (128 * 16 + 32) * 4;   // NW waves x (K ring + V ring) x DEC_PD stages of 8 KiB
-    constexpr int LDS_DEC = LDS_RING > LDS_MERGE ? LDS_RING : LDS_MERGE;
-    static bool attr_done[16] = {};
+    // SC_DEC_PD=1|2 pins the ring depth (A/B runs).  Default ONE stage per ring (64 KiB per workgroup): measured on the same box at a 49 k
+    // context 326.2 tokens/s against 323.7 with two stages (64 splits; 325.6 / 315.5 at 128), and 11.53 against 11.47 ms on the 26-sequence
+    // caption step - the run-ahead of a second stage buys nothing once the stream is all-DMA (profiles/r05_run_i_*)
+    static int pd_env = -1;
+    if (pd_env < 0) { const char* e = getenv("SC_DEC_PD"); pd_env = e ? atoi(e) : 0; }
+    const int pd = (pd_env == 1 || pd_env == 2) ? pd_env : 1;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
-    hipLaunchKernelGGL((k_attn_decode<128>), dim3((unsigned)nsplit, (unsigned)Hq, (unsigned)B), dim3(64 * DEC_NW), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
-                       (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs, Hq / Hkv);
+    auto go = [&](auto pdc) {
+        constexpr int PD = decltype(pdc)::value;
+        constexpr int LDS_RING = DEC_NW * 2 * PD * DCH * 128 * 2, LDS_MERGE = DEC_NW * (128 * 16 + 32) * 4;   // NW waves x (K ring + V ring) x PD stages of 8 KiB
+        constexpr int LDS_DEC = LDS_RING > LDS_MERGE ? LDS_RING : LDS_MERGE;
+        static bool attr_done[16] = {};
+        if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
+        hipLaunchKernelGGL((k_attn_decode<128, PD>), dim3((unsigned)nsplit, (unsigned)Hq, (unsigned)B), dim3(64 * DEC_NW), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
+                           (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs, Hq / Hkv);
+    };
+    if (pd == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
 }

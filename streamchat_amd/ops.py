@@ -440,6 +440,31 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out=None):
     return out
 
 
+def build_info() -> str:
+    """how libstreamchat_hip.so was built (sc_build_info): machine scheduler of attention.hip (or its FALLBACK), kernarg preload of the decode kernels"""
+    return _lib.load().sc_build_info().decode()
+
+
+def masked_stream(cu_first: int, cu_count: int, device=None):
+    """A torch stream restricted to the CUs [cu_first, cu_first + cu_count) (sc_stream_create_masked: hipExtStreamCreateWithCUMask; consecutive
+    CU-mask bits go round-robin over the XCDs, use multiples of 8).  Round 5: the HBM-bound answer decode on a few CUs beside the MFMA-bound
+    encode / prefill of the next segment on the rest.  The stream lives as long as the returned object."""
+    from ctypes import byref, c_void_p
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    h = c_void_p()
+    with torch.cuda.device(dev):
+        check(_lib.load().sc_stream_create_masked(int(cu_first), int(cu_count), 0, byref(h)), "sc_stream_create_masked")
+    s = torch.cuda.ExternalStream(h.value, device=dev)
+    s._sc_handle = h                    # (not destroyed on purpose: torch may still hold events recorded on it at interpreter exit)
+    s.cu_count = int(cu_count)
+    return s
+
+
+def set_cu_budget(n_cu: int):
+    """persistent launches (one workgroup per CU) size their grids for n_cu CUs (0: the whole device): set around launches on a masked stream"""
+    check(_lib.load().sc_set_cu_budget(int(n_cu)), "sc_set_cu_budget")
+
+
 def attention_workspace_bytes(B: int, Hq: int, Sq: int, nsplit: int, Dh: int) -> int:
     return B * Hq * Sq * nsplit * (Dh + 2) * 4 if nsplit > 1 else 0
 

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""CU-partitioned overlap of the HBM-bound answer decode (DecodeGraph, 49 k context) with MFMA-bound prefill work (the
+reference's reader / updater / QA threads).  Each job alone on the whole chip, each job alone on its CU partition, then both at once."""
+import argparse, copy, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from streamchat_amd import llm as LM, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ctx", type=int, default=49152)
+ap.add_argument("--tokens", type=int, default=192)
+ap.add_argument("--prefill", type=int, default=16384)
+ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--dec-cus", type=int, nargs="*", default=[32])
+a = ap.parse_args()
+cfg = LM.Qwen2ConfigLite(**LM.QWEN2_7B)
+lm = LM.Qwen2Model(LM.random_qwen2_state_dict(cfg, seed=0), cfg, max_seq=a.ctx + 1100, consume=True)
+lm.reset_cache()
+for l in range(cfg.layers):
+    lm.cache[l][:a.ctx].normal_(0, 0.5)
+lm2 = copy.copy(lm)                       # the same weights, its own KV cache and activation buffers: the NEXT segment's prefill
+lm2.cache, lm2.cache_len, lm2._buf_rows, lm2.max_seq = None, 0, 0, a.prefill + 8
+lm2.reset_cache()
+emb = (torch.randn(a.prefill, cfg.hidden, device="cuda") * 0.02).half()
+dg = LM.DecodeGraph(lm, max_new_tokens=1024, nsplit=64)
+lm.cache_len = a.ctx
+dg.start(1); dg.capture(); torch.cuda.synchronize()
+ncu = ops.device_info()["cu_count"]
+
+
+def decode(stream):
+    lm.cache_len = a.ctx
+    with torch.cuda.stream(stream):
+        dg.start(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(a.tokens):
+            dg.graph.replay()
+        e1.record(stream)
+    return e0, e1
+
+
+def prefill(stream, budget):
+    ops.set_cu_budget(budget)
+    try:
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(a.reps):
+                lm2.cache_len = 0
+                lm2.forward(emb)
+            e1.record(stream)
+    finally:
+        ops.set_cu_budget(0)
+    return e0, e1
+
+
+def ms(ev):
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1])
+
+
+cur = torch.cuda.current_stream()
+prefill(cur, 0); decode(cur); torch.cuda.synchronize()            # warm-up
+t_dec, t_pre = ms(decode(cur)), ms(prefill(cur, 0))
+out = dict(ctx=a.ctx, decode_tokens=a.tokens, prefill_tokens=a.prefill * a.reps, whole_chip=dict(decode_ms=round(t_dec, 1), decode_tok_s=round(a.tokens / t_dec * 1e3, 1),
+                                                                                                   prefill_ms=round(t_pre, 1), serial_ms=round(t_dec + t_pre, 1)))
+print(json.dumps(out), flush=True)
+for dc in a.dec_cus:
+    s_dec, s_main = ops.masked_stream(0, dc), ops.masked_stream(dc, ncu - dc)
+    s_dec.wait_stream(cur); s_main.wait_stream(cur)
+    d_alone = ms(decode(s_dec))
+    p_alone = ms(prefill(s_main, ncu - dc))
+    t0 = time.perf_counter()
+    ed = decode(s_dec)
+    ep = prefill(s_main, ncu - dc)
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+    d_both, p_both = ed[0].elapsed_time(ed[1]), ep[0].elapsed_time(ep[1])
+    print(json.dumps(dict(decode_cus=dc, main_cus=ncu - dc, decode_alone_ms=round(d_alone, 1), decode_alone_tok_s=round(a.tokens / d_alone * 1e3, 1),
+                          prefill_alone_ms=round(p_alone, 1), both=dict(wall_ms=round(wall, 1), decode_ms=round(d_both, 1), prefill_ms=round(p_both, 1)),
+                          speedup_vs_serial_whole_chip=round((t_dec + t_pre) / wall, 3))), flush=True)
