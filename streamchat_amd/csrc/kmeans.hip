@@ -18,6 +18,8 @@
 // The arithmetic order is the "SC-KM1" spec shared bit-for-bit with oracle/kmeans_oracle.c.
 // Compiled with -ffp-contract=off: every fma below is explicit.
 #include "sc_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -403,6 +405,256 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: update(i) + assign(i + 1) in ONE pass over X (fp16, D % 512 == 0, K <= 8, T <= 8 * RW).
+// km_assign and km_update each stream the whole [T, D] matrix: 2 n reads of X for n Lloyd iterations, 0.77 ms per iteration at T = 400,
+// K = 5, D = 2 064 384 against 0.27 ms for one read at the HBM rate.  Both need the chunk's T x 1 KiB slab; what stops a single pass is
+// where to keep 400 KiB between the two uses.  Here a persistent workgroup of EIGHT waves (two per SIMD, 256 registers each) keeps the
+// slab of one 512-column chunk IN REGISTERS - wave w owns rows [w RW, (w + 1) RW) as the raw 16 bytes per lane and row, 4 VGPRs each,
+// 200 of its 256 registers at RW = 50 - and walks chunks c = b, b + G, ...:
+//   update   SC-KM1 adds a cluster's rows in ascending order, one fp32 accumulator per column: the sum of cluster k travels through the
+//            waves in row order as a systolic chain - in phase p wave w adds its rows of cluster p - w to the running sums in LDS
+//            (K + 7 phases, one barrier each); which rows those are is a 64-bit ballot mask per cluster, built once per launch;
+//   finish   wave k divides cluster k by W_k (or takes the reseed row), writes C', the shift partial of the chunk and the new centroid
+//            slice into LDS;
+//   assign   every wave takes its rows once more - still in registers - against the K new slices (LDS): the lane partials of a row's K
+//            distances are reduced with an 8-value halving butterfly (levels 32, 16, 8 halve the values, 4, 2, 1 are plain xor-adds: the
+//            SC-KM1 tree, 8 live registers instead of butterfly64's 64);
+//   reload   the registers of row j are free the moment its distances are done: the row of the NEXT chunk is requested right there, so the
+//            stream runs under the whole assign pass and the next update finds its slab (mostly) landed.
+// One read of X per Lloyd iteration (n + 1 for n iterations with the plain first assign).  Arithmetic order is SC-KM1 throughout: labels,
+// centroids and exit iteration stay bit-identical to the two-kernel path and to oracle/kmeans_oracle.c.
+// ---------------------------------------------------------------------------------------------
+constexpr int FNW = 4;                                                        // waves per workgroup of the fused pass: one per SIMD, 512 registers each
+
+// (the empty asm makes the conversion depend on THIS point of the program: without it hipcc hoists the unpacking of every row out of the
+//  phase loop - 8 fp32 registers per row live across it, the slab's footprint tripled and spilled)
+__device__ __forceinline__ void unpack_h8(uint4& a, float (&o)[8]) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+    const sc_h8 v = __builtin_bit_cast(sc_h8, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+
+// First half of the SC-KM1 wave tree for 8 values per lane (this lane's partials of items 0..7): the levels 32, 16, 8 halve the values;
+// on return the lane holds ONE value: the partial of item (lane >> 3) over the lanes that differ from it in bits 5, 4, 3.
+__device__ __forceinline__ float butterfly8_hi(float (&v)[8], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                             // lanes ^ 32: items i | i + 4
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                             // lanes ^ 16: items i | i + 2
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const bool up = (lane & 8) != 0;                                          // lanes ^ 8: items 0 | 1
+    const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+    return keep + __shfl_xor(send, 8, 64);
+}
+
+// compile-time row loops (a `#pragma unroll` over 100 rows is refused by the unroller's budget, and raising the budget unrolls every other loop
+// of the kernel too - 300 k instructions; a recursive template is unrolled by construction and nothing else is)
+template <int J, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
+}
+
+template <int RW, int K, bool ASSIGN>                                         // rows per wave, clusters, whether the next iteration's partials are wanted
+__global__ __launch_bounds__(FNW * 64) void km_fused(const _Float16* __restrict__ X, float* __restrict__ Ca, float* __restrict__ Cb,
+                                                     const KmState* __restrict__ st, const float* __restrict__ w,
+                                                     const int* __restrict__ labels32, const float* __restrict__ W,
+                                                     const int* __restrict__ empty_rank, const int* __restrict__ reseed_idx, int n_reseed,
+                                                     float* __restrict__ dpart, float* __restrict__ partial, int T, int64_t D,
+                                                     int64_t nchunks) {
+    if (st->done) return;
+    constexpr int NM = (RW + 63) / 64;                                        // 64-row mask words per cluster
+    constexpr int GR = 4, NG = (RW + GR - 1) / GR;                            // rows whose butterflies interleave in the assign pass (8: 130 - 290 spilled registers)
+    __shared__ __attribute__((aligned(16))) float sums[K][CH];               // running column sums per cluster (the chain), then the new slices
+    const float* __restrict__ Cold = st->cur ? Cb : Ca;
+    float* __restrict__ Cnew = st->cur ? Ca : Cb;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r0 = wave * RW;
+    const int rbase = st->reseed_pos;
+    const size_t I = (size_t)T * (size_t)K;
+    // which of this wave's rows belong to cluster k: lane l of mask word m stands for row r0 + 64 m + l
+    unsigned long long mask[K][NM], live[NM];
+    float myw[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int jr = 64 * m + lane, myrow = r0 + jr;
+        const bool ok = jr < RW && myrow < T;
+        const int mylab = ok ? labels32[myrow] : -1;
+        myw[m] = (w && ok) ? w[myrow] : 1.0f;
+        live[m] = __ballot(ok);
+#pragma unroll
+        for (int k = 0; k < K; ++k) mask[k][m] = __ballot(mylab == k);
+    }
+
+    uint4 row[RW];
+    // one running pointer per load sweep (rows are consecutive; past T it stops advancing: the last row is re-read and never used) - a
+    // hundred precomputed row addresses are two hundred live scalars
+    const size_t row_first = (size_t)(r0 < T ? r0 : T - 1) * (size_t)D + (size_t)lane * 8;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    int64_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    {
+        const _Float16* xp = X + (size_t)c * CH + row_first;
+        static_for<0, RW>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(xp));
+            row[j] = make_uint4(v[0], v[1], v[2], v[3]);
+            if (r0 + j + 1 < T) xp += D;
+        });
+    }
+#pragma unroll 1
+    for (; c < nchunks; c += gridDim.x) {
+        const int64_t cn_next = c + gridDim.x;
+        const int64_t col = c * CH + lane * 8;
+        // ---- update: the ordered row sums as a chain through the waves ----
+#pragma unroll 1
+        for (int p = 0; p < K + FNW - 1; ++p) {
+            const int k = p - wave;
+            if (k >= 0 && k < K) {
+                float sacc[8];
+                if (wave == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sacc[e] = 0.f;
+                } else {
+                    const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sacc[e] = a[e]; sacc[4 + e] = b[e]; }
+                }
+                unsigned long long mk[NM];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {                                // mask[k] with a run-time k: a select chain over K scalar pairs
+                    mk[m] = 0;
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) mk[m] = (k == kk) ? mask[kk][m] : mk[m];
+                }
+                static_for<0, RW>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    __builtin_amdgcn_sched_barrier(0);                        // (one row at a time: interleaved, the unrolled rows' temporaries spill the slab)
+                    if ((mk[j >> 6] >> (j & 63)) & 1ull) {                    // (wave-uniform)
+                        float x[8];
+                        unpack_h8(row[j], x);
+                        if (w) {
+                            const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myw[j >> 6]), j & 63));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sacc[e] = sacc[e] + wt * x[e];        // mul, then add (no contraction: -ffp-contract=off)
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sacc[e] = sacc[e] + x[e];
+                        }
+                    }
+                });
+                *reinterpret_cast<sc_f4*>(&sums[k][lane * 8]) = sc_f4{sacc[0], sacc[1], sacc[2], sacc[3]};
+                *reinterpret_cast<sc_f4*>(&sums[k][lane * 8 + 4]) = sc_f4{sacc[4], sacc[5], sacc[6], sacc[7]};
+            }
+            __syncthreads();
+        }
+        // ---- finish: wave k % 4 owns cluster k: C' = sums / W (or the reseed row), shift partial, global store; the new slice replaces the sums ----
+#pragma unroll 1
+        for (int k = wave; k < K; k += FNW) {
+            float cn[8];
+            const float Wk = W[k];
+            if (Wk > 0.f) {
+                const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cn[e] = a[e] / Wk; cn[4 + e] = b[e] / Wk; }
+            } else {
+                const int pos = rbase + empty_rank[k];
+                int r = 0;
+                if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
+                if (r < 0 || r >= T) r = 0;
+                sc_load8<ScF16>(X, (size_t)r * (size_t)D + (size_t)col, cn);
+            }
+            float co[8];
+            sc_load8<ScF32>(Cold, (size_t)k * (size_t)D + (size_t)col, co);
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float d0 = co[e] - cn[e], d1 = co[e + 1] - cn[e + 1];
+                a0 = __builtin_fmaf(d0, d0, a0);
+                a1 = __builtin_fmaf(d1, d1, a1);
+            }
+            const float wp = sc_wave_tree_sum(a0 + a1);
+            if (lane == 0) dpart[(size_t)c * K + k] = wp;
+            sc_f4* dst = reinterpret_cast<sc_f4*>(Cnew + (size_t)k * (size_t)D + (size_t)col);
+            dst[0] = sc_f4{cn[0], cn[1], cn[2], cn[3]};
+            dst[1] = sc_f4{cn[4], cn[5], cn[6], cn[7]};
+            *reinterpret_cast<sc_f4*>(&sums[k][lane * 8]) = sc_f4{cn[0], cn[1], cn[2], cn[3]};
+            *reinterpret_cast<sc_f4*>(&sums[k][lane * 8 + 4]) = sc_f4{cn[4], cn[5], cn[6], cn[7]};
+        }
+        __syncthreads();
+        // ---- assign for the next iteration (against C', held in registers: 8 x K) + rolling reload of the slab for the next chunk ----
+        float cr[K][8];
+        if (ASSIGN) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cr[k][e] = a[e]; cr[k][4 + e] = b[e]; }
+            }
+        }
+        const bool more = cn_next < nchunks;                                  // (wave-uniform)
+        const _Float16* xn = X + (size_t)(more ? cn_next : c) * CH + row_first;
+        static_for<0, NG>([&](auto gc) {
+            constexpr int j0 = decltype(gc)::value * GR;
+            __builtin_amdgcn_sched_barrier(0);                                // (GR rows at a time: their butterflies interleave, the rest of the slab stays put)
+            float half[GR];                                                   // per row: the value left after the levels 32, 16, 8
+            static_for<0, GR>([&](auto jjc) {
+                constexpr int jj = decltype(jjc)::value, j = j0 + jj;
+                half[jj] = 0.f;
+                if constexpr (j < RW) {
+                    float x[8];
+                    if (ASSIGN) unpack_h8(row[j], x);
+                    if (more) {                                               // the registers of row j are free: next chunk's row j
+                        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(xn));
+                        row[j] = make_uint4(v[0], v[1], v[2], v[3]);
+                        if (r0 + j + 1 < T) xn += D;
+                    }
+                    if (ASSIGN) {
+                        float pv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) pv[k] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            sc_f2 acc = {0.f, 0.f};
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const sc_f2 xv = {x[e], x[e + 1]}, cv = {cr[k][e], cr[k][e + 1]};
+                                const sc_f2 d = xv - cv;
+                                acc = __builtin_elementwise_fma(d, d, acc);
+                            }
+                            pv[k] = acc.x + acc.y;
+                        }
+                        half[jj] = butterfly8_hi(pv, lane);
+                    }
+                }
+            });
+            if (ASSIGN) {
+                // second half of the tree (levels 4, 2, 1: plain xor-adds), the eight rows' chains interleaved
+#pragma unroll
+                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 4, 64);
+#pragma unroll
+                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 2, 64);
+#pragma unroll
+                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 1, 64);
+                const int k = lane >> 3;
+#pragma unroll
+                for (int jj = 0; jj < GR; ++jj) {
+                    const int j = j0 + jj;
+                    if (j < RW && ((live[j >> 6] >> (j & 63)) & 1ull) && (lane & 7) == 0 && k < K) partial[(size_t)c * I + (size_t)(r0 + j) * K + k] = half[jj];
+                }
+            }
+        });
+        __syncthreads();                                                      // `sums` is rewritten by the next chunk
+    }
+}
+
 // per-cluster squared shift totals ||C_k - C'_k||^2 of clusters [kb, kb + kn) from the per-chunk partials (SC-KM1: 32 contiguous chunk
 // segments in fp64, then the segment sums in fp64); result in tot[0..kn) (shared), valid after the trailing barrier
 __device__ __forceinline__ void km_shift_totals(const float* __restrict__ dpart, int K, int kb, int kn, int64_t nchunks, double* segs, double* tot) {
@@ -591,13 +843,36 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     }
     const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
     const dim3 rgrid((unsigned)((I + 255) / 256), NSEG);
+    // one-pass iterations (km_fused: update(i) + assign(i + 1) from a register-resident slab): fp16 rows, whole 512-column chunks, K = 5 or 8,
+    // T <= 400.  OPT-IN (SC_KM_FUSED=1): bit-identical to the two-kernel path (tests/test_gpu_kmeans_fused.py) and it does read X once per
+    // iteration, but it is SLOWER on MI355X - 1.47 ms per Lloyd iteration against 0.66 at T = 400, K = 5 (0.26 against 0.20 at T = 64, K = 8;
+    // profiles/r05_run_j_kmeans_fused.md): holding the 400 KiB slab takes one wave per SIMD with all 512 registers, and with nothing to
+    // switch to every dependent step of a row's distance tree (packed fma chain, three lane swaps, four LDS-crossbar shuffles) is paid at
+    // full latency - ~2000 cycles per row and wave, 6x the HBM time of the row.  km_assign hides exactly that with 8+ waves per SIMD.
+    static int fused_on = -1, n_cu = 0;
+    if (fused_on < 0) { const char* e = getenv("SC_KM_FUSED"); fused_on = (e && e[0] == '1') ? 1 : 0; }
+    const bool fused = fused_on && std::is_same<Tag, ScF16>::value && vec && D % CH == 0 && (K == 5 || K == 8) && T <= FNW * 100;
+    if (fused && n_cu == 0) { int dev = 0, n = 0; (void)hipGetDevice(&dev); n_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+    auto launch_fused = [&](int do_assign) {
+        const unsigned g = (unsigned)(nch < sc_launch_cu_count(n_cu) ? nch : sc_launch_cu_count(n_cu));
+        const int rw = (T + FNW - 1) / FNW;
+#define SC_KF3(RWV, KV, AV) hipLaunchKernelGGL((km_fused<RWV, KV, AV>), dim3(g), dim3(FNW * 64), 0, s, (const _Float16*)X, w.Ca, w.Cb, w.st, wts, w.labels32, w.W, \
+                                               w.empty_rank, reseed_idx, n_reseed, w.dpart, w.partial, T, D, nch)
+#define SC_KF2(RWV, KV) do { if (do_assign) SC_KF3(RWV, KV, true); else SC_KF3(RWV, KV, false); } while (0)
+#define SC_KF(RWV) do { if (K == 5) SC_KF2(RWV, 5); else SC_KF2(RWV, 8); } while (0)
+        if (rw <= 16) SC_KF(16); else if (rw <= 32) SC_KF(32); else if (rw <= 64) SC_KF(64); else SC_KF(100);
+#undef SC_KF
+#undef SC_KF2
+#undef SC_KF3
+    };
     for (int it = 0; it < max_iter; ++it) {
-        launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+        if (!fused || it == 0) launch_assign<Tag>(vec, X, w, T, D, K, nch, s);          // (fused: the partials of iteration it > 0 were written by km_fused(it - 1))
         hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 1);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
         hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
-        if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
-                                    w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
+        if (fused) launch_fused(it + 1 < max_iter ? 1 : 0);
+        else if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
+                                         w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
         else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
                                 w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
         hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dpart, w.st, K, nch, it, max_iter, tol, n_reseed);
