@@ -81,21 +81,22 @@ class TimedCaptioner:
         return out
 
     def generate_batch_with_image_embedding(self, inputs_list, image_embeddings_list, modalities=["image"], max_new_tokens=128, **kw):
+        # the PRODUCT method itself runs (llm.LlavaQwenForCausalLM.generate_batch_with_image_embedding); it times its two phases and reports
+        # the decode steps it really executed (EOS is checked every 16 steps: the graph replays up to 15 steps past the last sequence's end,
+        # and decode_s contains them - round 4 counted max(len) - 1 steps and re-implemented the method here)
         m, r = self.m, self.rec
-        sp = LM.resolve_sampling(m.generation_config, kw.get("do_sample", LM._UNSET), kw.get("temperature", LM._UNSET))
-        prompts = [m.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, img, modalities)[4][0] for ids, img in zip(inputs_list, image_embeddings_list)]
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        dec = LM.BatchDecoder(m.lm, prompts, max_new_tokens)                 # per-sequence prefill into one [B, cap, 2*dkv] cache per layer
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        toks = dec.generate(max_new_tokens, eos_token_id=m.eos_token_id, sampling=sp)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        n = [int(e.shape[0]) for e in prompts]
-        steps = max(len(t) for t in toks) - 1
-        r["chunks"] += len(prompts); r["prompt_tokens"] += sum(n); r["prefill_s"] += t1 - t0; r["decode_s"] += t2 - t1
-        r["decode_steps"] += steps; r["new_tokens"] += sum(len(t) for t in toks)
+        m.collect_batch_stats = True
+        try:
+            out = m.generate_batch_with_image_embedding(inputs_list, image_embeddings_list, modalities, max_new_tokens=max_new_tokens, **kw)
+        finally:
+            m.collect_batch_stats = False
+        st = m.batch_stats
+        n, steps = st["prompt_tokens"], st["steps_run"]
+        r["chunks"] += len(n); r["prompt_tokens"] += sum(n); r["prefill_s"] += st["prefill_s"]; r["decode_s"] += st["decode_s"]
+        r["decode_steps"] += steps; r["new_tokens"] += st["new_tokens"]; r["nsplit"] = st["nsplit"]
         r["prefill_flop"] += sum(2 * k * 6.53e9 + 2 * k * k * 3584 * 28 for k in n)                      # SURVEY 8(d) flop model (causal)
         r["decode_bytes"] += steps * (14.1e9 + sum(2 * 28 * 4 * 128 * (k + steps / 2) * 2 for k in n))     # per step: weights once + every sequence's K/V
-        return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
+        return out
 
 
 def measure_product(pipe, k, n_total):
@@ -118,7 +119,8 @@ def measure_product(pipe, k, n_total):
                              frac=round(r["prefill_flop"] / max(r["prefill_s"], 1e-9) / 1e12 / MFMA_PEAK_TF, 4)),
         caption_decode=dict(bound="hbm", achieved=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
-                            tokens_per_s_aggregate=round(r["new_tokens"] / max(r["decode_s"], 1e-9), 1), ms_per_decode_step=round(r["decode_s"] / max(r["decode_steps"], 1) * 1e3, 2)))
+                            tokens_per_s_aggregate=round(r["new_tokens"] / max(r["decode_s"], 1e-9), 1), ms_per_decode_step=round(r["decode_s"] / max(r["decode_steps"], 1) * 1e3, 2),
+                            decode_steps_per_step=r["decode_steps"] // k, split_kv=r.get("nsplit")))
 
 
 class Pipeline:
@@ -347,11 +349,15 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
         # ALL cores the process may use: the pool's hosts show 256 cores but run the container under a cgroup CPU quota of 16
         # (reported as `cpu_quota_cores`; tools/probe_host.py: 15.5 cores busy whatever is asked for), so the slice is dealt in batches of 4 frames to
         # one single-threaded worker process per usable core (oracle/torch_ref.parallel_plan / encode_frames_u8_parallel: same arithmetic per frame;
-        # 4.7 core-seconds per frame against 8-9 for multi-threaded forwards whose waiting threads burn the quota; worker start-up inside the timed region)
+        # 4.7 core-seconds per frame against 8-9 for multi-threaded forwards whose waiting threads burn the quota; worker start-up timed separately)
         workers, wthreads = R.parallel_plan(n_cpu_frames, batch=4)
         t0 = time.time()
-        feats = R.encode_frames_u8_parallel(sd, sp, u8, workers=workers, threads=wthreads, batch=4)      # the 64-frame slice = C1's encode
-        t_enc = time.time() - t0
+        tm = {}
+        feats = R.encode_frames_u8_parallel(sd, sp, u8, workers=workers, threads=wthreads, batch=4, timing=tm)      # the 64-frame slice = C1's encode
+        t_enc_wall = time.time() - t0
+        # steady state (first worker up -> last worker done): the start-up of the worker processes (spawn, `import torch`, sharing the fp32 weights) is a
+        # fixed cost that must not be multiplied by 1024 / 64 in the C2 / C3 extrapolation; both are reported
+        t_enc = tm.get("steady_s", t_enc_wall)
         quota = R.host_cpu_budget()[1]
     t_frame = t_enc / n_cpu_frames
     # ---- C1 in full: k-means(k=8) over the 64 encoded frames with the reference's broadcast formula, to its own exit ----
@@ -413,7 +419,7 @@ def cpu_baseline(pipe, n_cpu_frames, km_iters_gpu):
     return dict(value=round(n_frames / total, 5), unit="frames/s", cores=min(wthreads * workers, cores), cores_present=cores, cpu_quota_cores=quota, kind="port",
                 c1_frames_per_s=round(c1, 4), thread_sweep_s_per_frame=sweep, encode_workers=workers, threads_per_worker=wthreads, host_seconds=round(host_s, 1),
                 sample=f"oracle/torch_ref ViT-L+projector fp32 on a {n_cpu_frames}-frame slice: {workers} worker processes x {wthreads} threads on the {cores} cores present "
-                       f"(cgroup CPU quota of the container: {quota} cores), batches of 4 ({t_frame:.3f} s/frame for the whole host incl. worker start-up; one process: "
+                       f"(cgroup CPU quota of the container: {quota} cores), batches of 4 ({t_frame:.3f} s/frame for the whole host in steady state - first worker up to last worker done; {t_enc_wall:.1f} s incl. worker start-up; one process: "
                        f"{min(sweep.values()):.3f} s/frame at {threads} threads = best of the sweep {sweep} on a 4-frame batch) x{n_frames}; k-means and prefill legs: one process, "
                        f"{threads} threads; C1 RUN IN FULL: those {n_cpu_frames} frames + "
                        f"reference-formula k-means K=8 on their features to its exit ({it8 + 1} iterations, {t_km_c1:.1f} s) = {c1:.3f} frames/s; merge k-means: "
@@ -626,6 +632,19 @@ def main():
         stages["kmeans"] = dict(bound="hbm", kernel="km_assign + km_update", launches=kn, lloyd_passes=iters, avg_ms=round(kms / kn, 4),
                                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                                 frac_counting_both_reads_of_X=round(2 * gbs / HBM_PEAK_GBS, 4))
+    if kn and world == 1 and pipe.feats.shape[0] >= 400:
+        # the same merge k-means (T = 400, K = 5, D = 2 064 384, the step's own features) forced through all 10 Lloyd iterations (tol < 0): the
+        # synthetic stream cuts its scenes at the chunk size and converges at once; a real stream does not (tests/test_gpu_composed_shipped.py)
+        Xk = pipe.feats[:400].reshape(400, -1)
+        init10 = list(range(0, 400, 80))
+        ops.kmeans_fit(Xk, 5, init10, None, max_iter=10, tol=-1.0); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); _, _, _, info10 = ops.kmeans_fit(Xk, 5, init10, None, max_iter=10, tol=-1.0); e1.record(); torch.cuda.synchronize()
+        ms10 = e0.elapsed_time(e1)
+        b1 = 400 * Xk.shape[1] * 2 + 2 * 5 * Xk.shape[1] * 4
+        stages["kmeans_10_passes"] = dict(bound="hbm", kernel="km_assign + km_update", lloyd_passes=int(info10[0]) + 1, ms_total=round(ms10, 3), ms_per_pass=round(ms10 / 10, 4),
+                                          achieved=round(b1 / (ms10 / 10) / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b1 / (ms10 / 10) / 1e6 / HBM_PEAK_GBS, 4),
+                                          note="1x basis (one read of X per pass); the one-read-per-pass kernel (km_fused, SC_KM_FUSED=1) is bit-exact and slower: profiles/r05_run_j_kmeans_fused.md")
     per = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in sorted(prof.items())}
     enc_fps = n_total * a.steps / max(t_enc, 1e-9)
     names = dict(C1="C1: 64-frame stream, ViT-L encode + ONE weighted_kmeans_feature(k=8) over all frames (no LLM)",
@@ -676,7 +695,7 @@ def main():
                            frames_per_gpu=per_gpu, micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""),
                            weights="random-init", launcher="self (bare command)" if os.environ.get("SC_BENCH_SELF_LAUNCHED") == "1" else
                            ("torch.distributed.run" if world > 1 else "single process")),
-               roofline=roof, roofline_stages=stages, stages=per, power=power.summary())
+               roofline=roof, roofline_stages=stages, stages=per, power=power.summary(), build=ops.build_info())
     if pipe.last.get("path_text") is not None:      # what the question retrieved (and, on the sharded path, which global frames): equal for every GPU count
         import zlib
         sig = json.dumps(dict(path_text=list(pipe.last["path_text"]), wanted=pipe.last.get("wanted")))
@@ -695,6 +714,10 @@ def main():
         gb_tok = 14.1 + 2 * 28 * 4 * 128 * ctxlen * 2 / 1e9       # fp16 weights incl. lm_head + KV bytes per token
         out["decode_tokens_per_s"] = round(rate, 2)
         out["decode_tokens"] = a.decode_tokens
+        # BASELINE.json configs[2] in full: the step of the headline metric PLUS the 512-token answer (serial: a CU-partitioned overlap of the
+        # answer decode with the next segment's encode / prefill was built and measured slower, profiles/r05_run_i_overlap_cu_partition.jsonl)
+        out["c3_with_decode_frames_per_s"] = round(n_total / (ms_step / 1e3 + a.decode_tokens / rate), 2)
+        out["c3_with_decode_ms_per_step"] = round(ms_step + a.decode_tokens / rate * 1e3, 1)
         out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv / k_decode_qkv + k_attn_decode (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
                                                 unit="GB/s", frac=round(rate * gb_tok / HBM_PEAK_GBS, 4), gb_per_token=round(gb_tok, 2))
     if a.with_captions and full and world == 1 and config == "C3":

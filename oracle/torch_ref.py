@@ -85,15 +85,20 @@ def encode_images(sd_vit, sd_proj, pixel_values, *, heads, patch, num_layers, se
 # ---- the same encode on every host core: W worker processes x `threads` intra-op threads (one fp32 forward does not scale past
 # ~32 threads; a 256-core host finishes a 440-frame stream W times sooner).  Same arithmetic per frame: a batch is `batch` frames
 # wherever it runs.  Used by the composed-parity tests at the shipped geometry and by bench.py's cpu_baseline (all-cores leg).
-def _encode_worker(rank, workers, threads, sd_vit, sd_proj, u8, out, batch, heads, patch, num_layers):
+def _encode_worker(rank, workers, threads, sd_vit, sd_proj, u8, out, batch, heads, patch, num_layers, stamps=None):
+    import time
     torch.set_num_threads(threads)
     n = u8.shape[0]
     nb = (n + batch - 1) // batch
+    if stamps is not None:
+        stamps[rank, 0] = time.time()          # the worker is up (spawn + `import torch` + unpickling are behind it): steady-state work starts here
     with torch.no_grad():
         for b in range(rank, nb, workers):
             s, e = b * batch, min(n, (b + 1) * batch)
             x = torch.from_numpy(preprocess_u8(u8[s:e].numpy()))
             out[s:e] = encode_images(sd_vit, sd_proj, x, heads=heads, patch=patch, num_layers=num_layers)
+    if stamps is not None:
+        stamps[rank, 1] = time.time()
 
 
 def host_cpu_budget():
@@ -125,7 +130,7 @@ def parallel_plan(n_frames, batch=4):
     return workers, max(1, usable // workers)
 
 
-def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8, heads=16, patch=14, num_layers=24):
+def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8, heads=16, patch=14, num_layers=24, timing=None):
     """uint8 [N,H,W,3] (numpy) -> fp32 [N, P, d_out]: preprocess_u8 + encode_images in batches of `batch`, the batches dealt round-robin to
     `workers` spawned processes of `threads` threads each (weights, frames and the output live in shared memory)."""
     import os
@@ -137,10 +142,14 @@ def encode_frames_u8_parallel(sd_vit, sd_proj, u8, *, workers, threads, batch=8,
     img = u8.shape[1]
     out = torch.empty((u8.shape[0], (img // patch) ** 2, sp["2.weight"].shape[0]), dtype=torch.float32).share_memory_()
     workers = max(1, min(workers, (u8.shape[0] + batch - 1) // batch))
+    stamps = torch.zeros((workers, 2), dtype=torch.float64).share_memory_()
     if workers == 1:
-        _encode_worker(0, 1, threads, sv, sp, frames, out, batch, heads, patch, num_layers)
+        _encode_worker(0, 1, threads, sv, sp, frames, out, batch, heads, patch, num_layers, stamps)
     else:
-        mp.spawn(_encode_worker, args=(workers, threads, sv, sp, frames, out, batch, heads, patch, num_layers), nprocs=workers, join=True)
+        mp.spawn(_encode_worker, args=(workers, threads, sv, sp, frames, out, batch, heads, patch, num_layers, stamps), nprocs=workers, join=True)
+    if timing is not None:                        # `timing` (a dict): steady-state seconds = first worker up -> last worker done (start-up excluded)
+        timing["steady_s"] = float(stamps[:, 1].max() - stamps[:, 0].min())
+        timing["workers"] = workers
     return out
 
 

@@ -579,6 +579,7 @@ class BatchDecoder:
                 col = self.hist[:, :steps].cpu()
                 if all(any(int(v) in eos for v in col[b]) for b in range(B)):
                     break
+        self.steps_run = steps - 1                      # decode steps actually executed (EOS is only looked at every 16 steps: >= the longest kept sequence - 1)
         toks = self.hist[:, :steps].cpu().tolist()
         res = []
         for b in range(B):
@@ -638,8 +639,18 @@ class LlavaQwenForCausalLM:
         for ids, img in zip(inputs_list, image_embeddings_list):
             _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, img, modalities)
             prompts.append(embeds[0])
+        stats = getattr(self, "collect_batch_stats", False)          # bench.py: time the two phases of THIS method (not a copy of it)
+        if stats:
+            import time
+            torch.cuda.synchronize(); t0 = time.perf_counter()
         dec = BatchDecoder(self.lm, prompts, max_new_tokens)
+        if stats:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
         toks = dec.generate(max_new_tokens, eos_token_id=self.eos_token_id, generator=generator, sampling=sp)
+        if stats:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            self.batch_stats = dict(prompt_tokens=[int(e.shape[0]) for e in prompts], prefill_s=t1 - t0, decode_s=t2 - t1, steps_run=dec.steps_run,
+                                    new_tokens=sum(len(t) for t in toks), nsplit=dec.nsplit)
         return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
 
     def _next(self, logits, sp, prev, generator=None):
