@@ -66,6 +66,22 @@ def test_kmeans_exact_ties_pick_first():
     assert int(info[2]) >= 1                                                      # a reseed was consumed
 
 
+def test_near_tie_fixture_hip_equals_oracle():
+    """tests/golden/kmeans_near_tie.npz (the reference's own function on a constructed one-ulp near-tie, tools/make_golden_r05.py): the HIP
+    kernel takes the oracle's decision bit for bit - the strictly smaller squared distance - where the reference's argmin over fp32 `.sqrt()`
+    collapses the two and takes the first index (utiles.py:299-302; DESIGN section 2, arg-min footnote)."""
+    d = np.load(os.path.join(G, "kmeans_near_tie.npz"))
+    X, K, tie = d["X"], int(d["K"]), int(d["tie_row"])
+    T = X.shape[0]
+    ref = oracle.kmeans_fit(X.reshape(T, -1), K, d["init_idx"], d["reseed_idx"])
+    C, labels, wsum, info = ops.kmeans_fit(torch.from_numpy(X).cuda().reshape(T, -1), K, d["init_idx"], d["reseed_idx"])
+    lab = labels.cpu().numpy()
+    assert np.array_equal(lab, ref["labels"]) and np.array_equal(C.cpu().numpy(), ref["centroids"]) and int(info[0]) == ref["iters"]
+    assert lab[tie] == 1 and int(d["labels"][tie]) == 0 and np.array_equal(np.delete(lab, tie), np.delete(d["labels"], tie))
+    _, d2 = ops.kmeans_assign(torch.from_numpy(X).cuda().reshape(T, -1), torch.from_numpy(X.reshape(T, -1)[d["init_idx"]]).cuda(), return_dist2=True)
+    assert d2[tie, 0].item() == float(d["sq_dist_first"]) and d2[tie, 1].item() == float(d["sq_dist_second"])
+
+
 def test_weighted_kmeans_feature_dropin_shapes():
     d = np.load(CASES[0])
     X = torch.from_numpy(d["X"]).cuda().half()

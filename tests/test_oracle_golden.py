@@ -78,3 +78,31 @@ def test_reference_formula_restatement_matches_golden(path):
     C, labels, wsum, it = R.weighted_kmeans_reference_formula(X, int(d["K"]), d["init_idx"], d["reseed_idx"], w)
     assert np.array_equal(labels.numpy(), d["labels"]) and it == int(d["exit_iter"])
     np.testing.assert_allclose(C.numpy(), d["centroids"].reshape(int(d["K"]), -1), rtol=1e-5, atol=1e-6)
+
+
+def test_near_tie_pins_the_argmin_footnote():
+    """DESIGN section 2, arg-min footnote, pinned by data (fixture: tools/make_golden_r05.py running the reference's own
+    weighted_kmeans_feature).  One row has two fp32 squared distances ONE ulp apart whose fp32 square roots are equal: the reference's
+    argmin over `.sqrt()` (utiles.py:299-302) takes the first index, the oracle's argmin over the squared distances takes the strictly
+    smaller one.  Everything else of the run is identical, and the restated reference formula reproduces the reference exactly."""
+    import torch
+    from oracle import torch_ref as R
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "kmeans_near_tie.npz"))
+    X, K, tie = d["X"], int(d["K"]), int(d["tie_row"])
+    T = X.shape[0]
+    sA, sB = np.float32(d["sq_dist_first"]), np.float32(d["sq_dist_second"])
+    assert sB < sA and sA.view(np.int32) - sB.view(np.int32) == 1 and np.sqrt(sA) == np.sqrt(sB)      # the premise
+    # the premise holds on the fixture's rows: fp32 squared distances of the tie row to the two initial centroids
+    x, cA, cB = X[tie, 0], X[int(d["init_idx"][0]), 0], X[int(d["init_idx"][1]), 0]
+    f = lambda c: np.float32(np.float32((x[0] - c[0]) ** 2) + np.float32((x[1] - c[1]) ** 2))
+    assert f(cA) == sA and f(cB) == sB
+    r = oracle.kmeans_fit(X.reshape(T, -1), K, d["init_idx"], d["reseed_idx"], trace=True)
+    diff0 = np.nonzero(r["trace"][0] != d["trace"][0])[0]
+    assert list(diff0) == [tie] and d["trace"][0][tie] == 0 and r["trace"][0][tie] == 1               # the ONE divergent decision
+    assert int(d["labels"][tie]) == 0 and int(r["labels"][tie]) == 1                                  # both are Lloyd fixed points
+    assert np.array_equal(np.delete(r["labels"], tie), np.delete(d["labels"], tie)) and r["iters"] == int(d["exit_iter"])
+    # distances agree to the last bit: the oracle's fp64 totals ARE the fp32 values on this D = 2 fixture
+    d2 = oracle.kmeans_dist2(X.reshape(T, -1), X.reshape(T, -1)[d["init_idx"]])
+    assert d2[tie, 0] == float(sA) and d2[tie, 1] == float(sB)
+    C, labels, wsum, it = R.weighted_kmeans_reference_formula(torch.from_numpy(X).reshape(T, -1), K, d["init_idx"], d["reseed_idx"], None)
+    assert np.array_equal(labels.numpy(), d["labels"]) and it == int(d["exit_iter"])
