@@ -98,6 +98,13 @@ __global__ void k_attn_combine(const float* __restrict__ part, _Float16* __restr
 // in the layout k_attn_combine reads.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DCH = 32;                            // kv rows per chunk
+// Diagnostic build only (-DSC_DEC_TRACE, tools/trace_decode_attn.py): five 100-MHz wall-clock stamps per wave of the LAST launch
+#ifdef SC_DEC_TRACE
+__device__ unsigned long long sc_dec_trace_buf[8192 * 8];
+#define DEC_STAMP(i) do { if (lane == 0) sc_dec_trace_buf[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 2048 * (DEC_NW * 8) + wave * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DEC_STAMP(i) do { } while (0)
+#endif
 #ifndef SC_DEC_ABL
 #define SC_DEC_ABL 0
 #endif
@@ -126,6 +133,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
     // grid = (split, head, batch): no integer division in the prologue (round 4 decoded a flat block index with three of them, ~60
     // scalar instructions in front of the first memory request of a 22 us kernel)
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    DEC_STAMP(0);
     const int hk = group == 1 ? h : h / group;                                          // group = Hq / Hkv (1 when the caller packs the G heads as query rows)
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
     // chunks of this split, then of this wave: EVEN shares (sizes differ by at most one chunk).  Round 4 cut ceil(nch / nsplit) chunks per
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
     if (any) {
 #pragma unroll
         for (int u = 0; u < DEC_PD; ++u) { issue_k(c_lo + u); issue_v(c_lo + u); }          // (past c_hi: zero extent -> no traffic)
+        DEC_STAMP(1);
         for (int c = c_lo; c < c_hi; ++c) {
             const unsigned stage = (unsigned)((c % DEC_PD) * CHB);
 #if SC_DEC_ABL == 1                 // ablation: the stream alone (waits + re-issue, no LDS reads, no arithmetic)
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]),
                                                   "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]) :: "memory");
+            if (c == c_lo) DEC_STAMP(2);
             issue_k(c + DEC_PD);                                   // K(c)'s stage is free: its fragments are in registers
             sc_f4 s[2];
 #pragma unroll
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may still be in flight when the rings are reused / the block ends
+    DEC_STAMP(3);
     // ---- merge the four waves of the split through LDS (aliases the rings: every wave is done with its own) ----
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
         pp[d] = acc;
         if (d == 0) { pp[DH] = M; pp[DH + 1] = l; }
     }
+    DEC_STAMP(4);
 }
 
 }  // namespace
@@ -329,6 +341,10 @@ const char* sc_decode_build_tag() {
     return "decode=plain";
 #endif
 }
+
+#ifdef SC_DEC_TRACE
+extern "C" int sc_dec_trace_read(void* dst, int bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sc_dec_trace_buf), bytes); }
+#endif
 
 // launchers used by attention.hip
 void sc_attn_combine_launch(int Dh, const float* part, void* out, int ldo, int B, int Sq, int Hq, int nsplit, int o_hs, long o_bs, hipStream_t s) {

@@ -148,7 +148,12 @@ class MMProjector:
         self.d_out = self.w2.shape[0]
         self._mid = None
 
-    def __call__(self, hidden, n, P, drop_cls=True, out=None):
+    def __call__(self, hidden, n, P, drop_cls=True, out=None, pool=1):
+        """`pool` = r > 1 (reference compress_spatial_features utiles.py:264-289 / --compress_rate): the r x r spatial mean of the
+        projected token map.  The mean commutes with the last Linear (pool(mid) W2^T + b2 = pool(mid W2^T + b2)), so it is applied to the
+        post-GELU activations and the second GEMM runs on 1 / r^2 of the rows: the pooled features cost LESS than the unpooled ones, where an
+        epilogue on the full-size GEMM would only save the store.  Rounding: one fp16 rounding of the pooled activations (fp32 mean) instead of
+        one of every unpooled output - inside the encoder tolerance (tests/test_gpu_vision.py)."""
         M = n * P
         if self._mid is None or self._mid.shape[0] < M:
             self._mid = torch.empty((M, self.w0.shape[0]), dtype=torch.float16, device=hidden.device)
@@ -157,29 +162,37 @@ class MMProjector:
         # value, nothing to overlap them with at one wave per SIMD) ran 3.36 ms - slower; reverted (profiles/r03_bench_kernel_stats.md history).
         rows = (P, P + 1, 1) if drop_cls else None
         mid = ops.gemm(hidden, self.w0, self.b0, epilogue="gelu", out=self._mid[:M], a_rows=rows, M=M)
+        if pool > 1:
+            if not drop_cls:
+                raise ops.StreamChatHipError("MMProjector: spatial pooling needs the patch grid alone (select_feature 'patch')")
+            mid = ops.avgpool_tokens(mid.view(n, P, -1), pool).view(-1, mid.shape[1])
         return ops.gemm(mid, self.w2, self.b2, out=out)
 
 
 class FrameEncoder:
     """`encode_images` of the reference (llava_arch.py:179-184): vision tower -> projector -> identity resampler."""
 
-    def __init__(self, tower: CLIPVisionTower, projector: MMProjector, micro_batch=512):
-        self.tower, self.projector, self.micro_batch = tower, projector, micro_batch
+    def __init__(self, tower: CLIPVisionTower, projector: MMProjector, micro_batch=512, compress_rate=1):
+        """compress_rate r > 1: every frame leaves the encoder as (grid // r)^2 tokens, the r x r spatial means of its projected patch map (the
+        reference's `compress_spatial_features(feature_list, compress_rate)`, utiles.py:264-289, fused into the projector)."""
+        self.tower, self.projector, self.micro_batch, self.compress_rate = tower, projector, micro_batch, int(compress_rate)
 
     def _run(self, n_total, fill_patches, out):
         c = self.tower.cfg
         P = c.num_patches
         drop = self.tower.select_feature == "patch"                      # clip_encoder.py:53-58
         tokens = P if drop else P + 1
+        r = self.compress_rate
+        out_tokens = tokens if r <= 1 else (int(round(math.sqrt(P))) // r) ** 2
         if out is None:
-            out = torch.empty((n_total, tokens, self.projector.d_out), dtype=torch.float16, device=self.tower.device)
+            out = torch.empty((n_total, out_tokens, self.projector.d_out), dtype=torch.float16, device=self.tower.device)
         mb = min(self.micro_batch, n_total)
         self.tower._buffers(mb)
         for s in range(0, n_total, mb):
             n = min(mb, n_total - s)
             fill_patches(s, n, self.tower._buf["patches"])
             h = self.tower.hidden_from_patches(n)
-            self.projector(h, n, tokens, drop_cls=drop, out=out[s:s + n].view(n * tokens, -1))
+            self.projector(h, n, tokens, drop_cls=drop, out=out[s:s + n].view(n * out_tokens, -1), pool=r)
         return out
 
     def encode_images(self, images, out=None):

@@ -112,3 +112,23 @@ def test_video_reader_host_frames_go_through_async_ingest_and_match_device_frame
     assert len(a) == len(b) > 0 and a[0].shape == (1, 16, 256)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert a[1].data_ptr() - a[0].data_ptr() == a[0].numel() * 2                  # views into ONE contiguous bank
+
+
+@pytest.mark.parametrize("r", [2, 4])
+def test_compress_rate_fused_into_the_projector(r):
+    """FrameEncoder(compress_rate=r): the r x r spatial mean applied to the post-GELU activations, second projector GEMM on
+    1 / r^2 of the rows == the reference's compress_spatial_features (utiles.py:264-289: F.avg_pool2d of the projected [B, D, P, P] map) on the
+    unpooled features, within the encoder tolerance - against the HF golden features pooled in fp32 and against our own unpooled path + the
+    drop-in utiles.compress_spatial_features."""
+    d, sd, sp, cfg = _tiny()
+    px = torch.from_numpy(d["pixel_values"]).cuda().half()
+    pooled = V.FrameEncoder(V.CLIPVisionTower(sd, cfg), V.MMProjector(sp), compress_rate=r).encode_images(px)
+    g = 4 // r
+    assert pooled.shape == (3, g * g, 256)
+    ref = torch.from_numpy(d["projected"])                                       # [3, 16, 256] fp32 from the HF modules
+    ref = torch.nn.functional.avg_pool2d(ref.reshape(3, 4, 4, 256).permute(0, 3, 1, 2), (r, r)).permute(0, 2, 3, 1).reshape(3, g * g, 256)
+    assert_close_fp16(pooled, ref, what=f"pooled projector r={r} vs avg_pool2d of the HF golden")
+    from streamchat_amd import utiles as U
+    full = V.FrameEncoder(V.CLIPVisionTower(sd, cfg), V.MMProjector(sp)).encode_images(px)
+    two_step = torch.cat(U.compress_spatial_features([full[i:i + 1] for i in range(3)], r))
+    assert_close_fp16(pooled, two_step.float(), max_rel=2e-3, rms_rel=1.5e-3, what=f"pooled projector r={r} vs encode + compress_spatial_features")

@@ -7,7 +7,7 @@ import torch
 from streamchat_amd import ops
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 NW = 6            # distinct weight copies cycled, so that nothing is served from the Infinity Cache
-for (N, K, epi, f32, name) in [(3584, 3584, "none", True, "q(f32)"), (1024, 3584, "none", True, "kv(f32)"), (3584, 3584, "none", False, "o+res"),
+for (N, K, epi, f32, name) in [(3584, 3584, "none", True, "q(f32)"), (1024, 3584, "none", True, "kv(f32)"), (3584, 3584, "none", False, "o+res"), (4608, 3584, "none", True, "qkv(f32)"),
                                (37888, 3584, "swiglu", False, "gate_up"), (3584, 18944, "none", False, "down+res"), (152064, 3584, "none", True, "lm_head")]:
     nw = 2 if N > 100000 else NW
     ws = [(torch.rand(N, K, device="cuda") - 0.5).half() for _ in range(nw)]
@@ -22,4 +22,4 @@ for (N, K, epi, f32, name) in [(3584, 3584, "none", True, "q(f32)"), (1024, 3584
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); [g.replay() for _ in range(5)]; e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 60
-    print(json.dumps(dict(kernel=os.environ.get("SC_GEMM_KERNEL", "skinny"), M=M, name=name, N=N, K=K, us=round(us, 2), TBps=round(N * K * 2 / us / 1e6, 2))))
+    print(json.dumps(dict(kernel=os.environ.get("SC_GEMM_KERNEL", "skinny"), waves=os.environ.get("SC_SKINNY_WAVES", "rule"), M=M, name=name, N=N, K=K, us=round(us, 2), TBps=round(N * K * 2 / us / 1e6, 2))))
