@@ -134,6 +134,14 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
     // scalar instructions in front of the first memory request of a 22 us kernel)
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     DEC_STAMP(0);
+#ifdef SC_DEC_TRACE
+    {   // where this wave runs: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) and the XCC id
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) sc_dec_trace_buf[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 2048 * (DEC_NW * 8) + wave * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int hk = group == 1 ? h : h / group;                                          // group = Hq / Hkv (1 when the caller packs the G heads as query rows)
     const int kv_valid = kv_len ? min(kv_len[b], Skv) : Skv;
     // chunks of this split, then of this wave: EVEN shares (sizes differ by at most one chunk).  Round 4 cut ceil(nch / nsplit) chunks per

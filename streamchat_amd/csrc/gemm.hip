@@ -993,21 +993,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
 // SwiGLU and stores.  C/D layout of v_mfma_f32_16x16x32_f16: lane holds D[n = (lane>>4)*4 + r][m = lane&15], i.e. one
 // (g0, g1, u0, u1) quad of the interleaved SwiGLU weight per lane.
 // ------------------------------------------------------------------------------------------------------------------
-// NWV = waves per workgroup = K-slices of a strip (4, 8 or 16).  Round 5: one strip per workgroup and four waves leave a CU with 4 waves
-// and at most ~30 KB of weights in flight - the 3584-row projections of the batched caption decode (o, down, fused q|k|v: 224-288
-// strips, less than one workgroup per CU) ran at 1.6 - 2.7 TB/s where the batch-1 GEMV of the same weights, with 14 waves per CU,
-// reaches 4.7 - 6.1.  More K-slices per strip = more waves per CU streaming the same bytes; the partial tiles are summed in wave order
-// (wave 0's accumulator, then red[0], red[1], ...): the result depends on NWV, which sc_skinny_waves() fixes per (N, K) for the
-// run-time-loop kernel and the straight-line one alike.
-template <int EPI, bool OUT_F32, int MG, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV) void k_gemm_skinny(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+template <int EPI, bool OUT_F32, int MG>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
                                                      void* __restrict__ Cout, int ldc, int M, int N, int K) {
-    __shared__ float red[NWV - 1][MG][4][64];
+    __shared__ float red[3][MG][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rl = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int kc = K / NWV, k_lo = wave * kc;
+    const int kc = K / 4, k_lo = wave * kc;
     const _Float16* wp = W + (size_t)(n0 + rl) * (size_t)K + k_lo + g * 8;
     const _Float16* xp[MG];
 #pragma unroll
@@ -1050,12 +1044,7 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm_skinny(const _Float16* __rest
     for (int mg = 0; mg < MG; ++mg) {
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = acc[mg][r];
-#pragma unroll
-            for (int w = 0; w < NWV - 1; ++w) t += red[w][mg][r][lane];
-            v[r] = t + (bias ? (float)bias[n + r] : 0.f);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = acc[mg][r] + red[0][mg][r][lane] + red[1][mg][r][lane] + red[2][mg][r][lane] + (bias ? (float)bias[n + r] : 0.f);
         const int m = mg * 16 + rl;
         if (m >= M) continue;
         if (EPI == SC_EPI_SWIGLU) {
@@ -1080,16 +1069,16 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm_skinny(const _Float16* __rest
 //   [x fragments of batch 0] [W of batch 0] | per batch b: [x of b + 1] [W of b + 1]  ->  MFMAs of batch b
 // (x first: it comes out of L2 and is back long before the weights), same k order per accumulator as the loop above: the sums are
 // bit-identical to k_gemm_skinny's.
-template <int EPI, bool OUT_F32, int MG, int KW, int BT, int NWV = 4>      // KW = k-steps (of 32) per wave = K / NWV / 32
-__global__ __launch_bounds__(64 * NWV) void k_gemm_skinny_u(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+template <int EPI, bool OUT_F32, int MG, int KW, int BT>      // KW = k-steps (of 32) per wave = K / 4 / 32
+__global__ __launch_bounds__(256) void k_gemm_skinny_u(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                        const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
                                                        void* __restrict__ Cout, int ldc, int M, int N) {
-    constexpr int K = KW * 32 * NWV, NB = (KW + BT - 1) / BT;
-    __shared__ float red[NWV - 1][MG][4][64];
+    constexpr int K = KW * 32 * 4, NB = (KW + BT - 1) / BT;
+    __shared__ float red[3][MG][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rl = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int k_lo = wave * (K / NWV);
+    const int k_lo = wave * (K / 4);
     const _Float16* wp = W + (size_t)(n0 + rl) * (size_t)K + k_lo + g * 8;
     const _Float16* xp[MG];
 #pragma unroll
@@ -1144,12 +1133,7 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm_skinny_u(const _Float16* __re
     for (int mg = 0; mg < MG; ++mg) {
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = acc[mg][r];
-#pragma unroll
-            for (int w = 0; w < NWV - 1; ++w) t += red[w][mg][r][lane];
-            v[r] = t + (bias ? (float)bias[n + r] : 0.f);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = acc[mg][r] + red[0][mg][r][lane] + red[1][mg][r][lane] + red[2][mg][r][lane] + (bias ? (float)bias[n + r] : 0.f);
         const int m = mg * 16 + rl;
         if (m >= M) continue;
         if (EPI == SC_EPI_SWIGLU) {
@@ -1280,17 +1264,6 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_x(const _Float16* __restric
     }
 }
 
-// K-slices (= waves) per 16-row strip of the skinny kernels: 4 where the strips alone fill the chip (gate/up, lm_head), otherwise as
-// many as K divides into whole 32-element k-steps, up to 16.  SC_SKINNY_WAVES=4|8|16 pins it (A/B runs).
-static int sc_skinny_waves(int N, int K, int n_cu) {
-    static int pin = -1;
-    if (pin < 0) { const char* e = getenv("SC_SKINNY_WAVES"); pin = e ? atoi(e) : 0; }
-    int w = (N / 16 >= 2 * n_cu) ? 4 : 16;
-    if (pin == 4 || pin == 8 || pin == 16) w = pin;
-    while (w > 4 && K % (32 * w) != 0) w >>= 1;
-    return w;
-}
-
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
@@ -1324,21 +1297,8 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
                 SC_CHECK_LAUNCH("sc_gemm_f16");
                 return SC_OK;
             }
-            // few strips (N / 16 below two per CU: o, down, the fused q|k|v of the batched decode): more K-slices per strip, see k_gemm_skinny
-            const int nwv = sc_skinny_waves(N, K, n_cu_x[dev]);
-            if constexpr (EPI == SC_EPI_NONE) if (nwv > 4) {
-#define SC_LSW(F32, MGV, KWV, BTV, NW) hipLaunchKernelGGL((k_gemm_skinny_u<EPI, F32, MGV, KWV, BTV, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
-                                                          (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N)
-#define SC_LSW2(KWV, BT1, BT2, NW) do { if (M <= 16) { if (out_f32) SC_LSW(true, 1, KWV, BT1, NW); else SC_LSW(false, 1, KWV, BT1, NW); } \
-                                        else { if (out_f32) SC_LSW(true, 2, KWV, BT2, NW); else SC_LSW(false, 2, KWV, BT2, NW); } } while (0)
-                if (K == 3584) { if (nwv == 16) SC_LSW2(7, 7, 7, 16); else SC_LSW2(14, 14, 14, 8); }
-                else { if (nwv == 16) SC_LSW2(37, 6, 4, 16); else SC_LSW2(74, 12, 8, 8); }
-#undef SC_LSW2
-#undef SC_LSW
-                SC_CHECK_LAUNCH("sc_gemm_f16");
-                return SC_OK;
-            }
-            // (one strip per workgroup, four waves: the whole K-quarter of a wave in flight at once - 28 weight + 28 MG activation fragments per lane)
+            // (one strip per workgroup and at most ~one workgroup per CU: the whole K-quarter of a wave in flight at once - 28 weight + 28 MG
+            //  activation fragments per lane)
             if (K == 3584) { if (M <= 16) { if (out_f32) SC_LSU(true, 1, 28, 28); else SC_LSU(false, 1, 28, 28); }
                              else { if (out_f32) SC_LSU(true, 2, 28, 7); else SC_LSU(false, 2, 28, 7); } }
             else { if (M <= 16) { if (out_f32) SC_LSU(true, 1, 148, 8); else SC_LSU(false, 1, 148, 8); }
@@ -1347,19 +1307,11 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
         }
-        {
-            static int n_cu_g[16] = {};
-            if (n_cu_g[dev] == 0) { int n = 0; n_cu_g[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
-            const int nwv = (EPI == SC_EPI_NONE) ? sc_skinny_waves(N, K, n_cu_g[dev]) : 4;
-#define SC_LSK(F32, MGV, NW) hipLaunchKernelGGL((k_gemm_skinny<EPI, F32, MGV, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
-                                                  (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K)
-#define SC_LSK2(NW) do { if (M <= 16) { if (out_f32) SC_LSK(true, 1, NW); else SC_LSK(false, 1, NW); } \
-                         else { if (out_f32) SC_LSK(true, 2, NW); else SC_LSK(false, 2, NW); } } while (0)
-            if constexpr (EPI == SC_EPI_NONE) { if (nwv == 16) SC_LSK2(16); else if (nwv == 8) SC_LSK2(8); else SC_LSK2(4); }
-            else SC_LSK2(4);
-#undef SC_LSK2
+#define SC_LSK(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny<EPI, F32, MGV>), grid, block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
+                                              (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K)
+        if (M <= 16) { if (out_f32) SC_LSK(true, 1); else SC_LSK(false, 1); }
+        else { if (out_f32) SC_LSK(true, 2); else SC_LSK(false, 2); }
 #undef SC_LSK
-        }
         SC_CHECK_LAUNCH("sc_gemm_f16");
         return SC_OK;
     }
