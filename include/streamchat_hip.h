@@ -52,8 +52,9 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *   5  round 5: + sc_build_info; + sc_stream_create_masked / sc_stream_destroy / sc_set_cu_budget (CU-partitioned streams: the HBM-bound
  *      answer decode beside the MFMA-bound encode / prefill of the next segment); sc_attention_f16 decode path: grid and chunk shares
  *      changed (results of a split-KV call differ in the last bit from version 4's, every caller sees one consistent kernel)
+ *   6  round 5: + sc_rope_qkv_rows_f16 (the batched decode step's rotary + KV-append in one launch)
  */
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 
 int sc_abi_version(void);
 const char* sc_last_error(void);
@@ -218,6 +219,13 @@ int sc_rope_qk_row_f16(void* q, int q_heads, void* cache, int ld, const int32_t*
 int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, float scale, sc_stream_t stream);
 int sc_rope_f32in_f16(const float* x, int ldx, const float* tab, int tab_rows, const int32_t* positions, int pos0, int rows, int heads, int Dh,
                       int plain_cols, void* out, int ldo, sc_stream_t stream);
+/* v6: one new token for each of B sequences (batched decode, llm.BatchDecoder; reference utiles.py:539-559 runs these generates one by one).
+ * x [B, ldx] fp32 = fused q|k|v projection + bias ((q_heads + 2 kv_heads) * Dh columns).  q heads rotated with tab_q at positions[b] -> q_out
+ * [B, ldq]; k heads rotated with tab_k and the v columns cast -> row positions[b] of sequence b's cache (cache + b * cache_batch_stride +
+ * positions[b] * cache_ld elements; rows [K of kv_heads | V of kv_heads]).  Bit-identical to sc_rope_f32in_f16 on the q and on the k|v columns
+ * followed by a row scatter.  positions are device data (graph-replayable) and clamped to the table / to cache_rows. */
+int sc_rope_qkv_rows_f16(const float* x, int ldx, const float* tab_q, const float* tab_k, int tab_rows, const int32_t* positions, int B, int q_heads,
+                         int kv_heads, int Dh, void* q_out, int ldq, void* cache, int64_t cache_batch_stride, int cache_ld, int cache_rows, sc_stream_t stream);
 int sc_decode_qkv_tab_f16(const void* Wq, const void* Wkv, const void* bq, const void* bkv, const void* x, const void* rms_gamma,
                           float rms_eps, void* q_out, void* cache, int cache_ld, const int32_t* pos, int q_heads, int kv_heads, int Dh,
                           int K, const float* tab_q, const float* tab_k, int tab_rows, sc_stream_t stream);

@@ -16,7 +16,7 @@ class StreamChatHipError(RuntimeError):
 
 
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
-ABI_VERSION = 5            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
+ABI_VERSION = 6            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),
@@ -50,6 +50,7 @@ SIGNATURES = {
     "sc_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sc_gemm_headed_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "sc_rope_table_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "sc_rope_qkv_rows_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sc_rope_f32in_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sc_decode_qkv_tab_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                       c_int, c_void_p, c_void_p, c_int, c_void_p]),

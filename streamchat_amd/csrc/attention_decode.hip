@@ -132,7 +132,11 @@ __global__ __launch_bounds__(64 * DEC_NW) void k_attn_decode(const _Float16* __r
     const int rl = lane & 15, g = lane >> 4;
     // grid = (split, head, batch): no integer division in the prologue (round 4 decoded a flat block index with three of them, ~60
     // scalar instructions in front of the first memory request of a 22 us kernel)
+#ifdef SC_DEC_HROT          // diagnostic: which head a grid row works on (does a slow row follow the grid position or the head's addresses?)
+    const int split = blockIdx.x, h = (blockIdx.y + SC_DEC_HROT) % gridDim.y, b = blockIdx.z;
+#else
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+#endif
     DEC_STAMP(0);
 #ifdef SC_DEC_TRACE
     {   // where this wave runs: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) and the XCC id

@@ -1288,7 +1288,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // activations resident in registers, persistent over strips (k_gemm_skinny_x): where a workgroup gets at least two strips (gate/up,
             // lm_head); with one strip per workgroup (the 3584-row projections) loading x first only delays the weights: k_gemm_skinny_u
             if (K == 3584 && xres && N / 16 >= 2 * n_cu_x[dev]) {
-                const int strips = N / 16, gx = sc_launch_cu_count(n_cu_x[dev]);
+                const int strips = N / 16, gx = sc_launch_cu_count(n_cu_x[dev], s);
 #define SC_LSX(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny_x<EPI, F32, MGV>), dim3((unsigned)gx), block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
                                             (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, strips / gx, strips % gx)
                 if (M <= 16) { if (out_f32) SC_LSX(true, 1); else SC_LSX(false, 1); }
@@ -1341,7 +1341,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
             if (n_cu_dev[dev] <= 0) n_cu_dev[dev] = 256;
         }
-        const int n_cu = sc_launch_cu_count(n_cu_dev[dev]);          // (sc_set_cu_budget: a CU-masked stream gets a persistent grid of its own size)
+        const int n_cu = sc_launch_cu_count(n_cu_dev[dev], s);          // (sc_set_cu_budget: a CU-masked stream gets a persistent grid of its own size)
         const int nt_all = tM * tN, nk2 = K / BK2;
         // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
         static int fat = -1;
@@ -1409,7 +1409,7 @@ int launch_headed(const void* A, int lda, const void* W, const void* bias, void*
         if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
         if (n_cu_dev[dev] <= 0) n_cu_dev[dev] = 256;
     }
-    const int n_cu = sc_launch_cu_count(n_cu_dev[dev]), tM = (M + BM2 - 1) / BM2, tN = N / BN2, nt_all = tM * tN;
+    const int n_cu = sc_launch_cu_count(n_cu_dev[dev], s), tM = (M + BM2 - 1) / BM2, tN = N / BN2, nt_all = tM * tN;
     const bool fp = nt_all > n_cu;                                   // persistent walk once there are more tiles than CUs (as in launch_gemm)
     const int gm_sel = tN > 16 ? 4 : SC_GEMM_GM;
     static bool attr[16][2] = {};

@@ -854,7 +854,7 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     const bool fused = fused_on && std::is_same<Tag, ScF16>::value && vec && D % CH == 0 && (K == 5 || K == 8) && T <= FNW * 100;
     if (fused && n_cu == 0) { int dev = 0, n = 0; (void)hipGetDevice(&dev); n_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
     auto launch_fused = [&](int do_assign) {
-        const unsigned g = (unsigned)(nch < sc_launch_cu_count(n_cu) ? nch : sc_launch_cu_count(n_cu));
+        const unsigned g = (unsigned)(nch < sc_launch_cu_count(n_cu, s) ? nch : sc_launch_cu_count(n_cu, s));
         const int rw = (T + FNW - 1) / FNW;
 #define SC_KF3(RWV, KV, AV) hipLaunchKernelGGL((km_fused<RWV, KV, AV>), dim3(g), dim3(FNW * 64), 0, s, (const _Float16*)X, w.Ca, w.Cb, w.st, wts, w.labels32, w.W, \
                                                w.empty_rank, reseed_idx, n_reseed, w.dpart, w.partial, T, D, nch)

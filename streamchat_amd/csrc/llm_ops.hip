@@ -165,6 +165,49 @@ __global__ __launch_bounds__(256) void k_rope_f32in(const float* __restrict__ x,
     }
 }
 
+// The three launches behind a BATCHED decode step's q|k|v projection in one (round 5, ABI 6): x [B, (Hq + 2 Hkv) Dh] fp32 = fused projection +
+// bias of one new token per sequence.  q heads rotated with tab_q (scaled table) -> q_out [B, Hq Dh]; k heads rotated with tab_k and the v
+// columns cast -> row pos[b] of sequence b's KV cache (cache + b * cache_bs + pos[b] * cache_ld).  Element for element the arithmetic of
+// k_rope_f32in (same fma sequence, one rounding): bit-identical to sc_rope_f32in_f16 x 2 + a row scatter.
+__global__ __launch_bounds__(256) void k_rope_qkv_rows(const float* __restrict__ x, int ldx, const float* __restrict__ tab_q, const float* __restrict__ tab_k, int tab_rows,
+                                                       const int* __restrict__ pos, int B, int Hq, int Hkv, int Dh, _Float16* __restrict__ q_out, int ldq,
+                                                       _Float16* __restrict__ cache, long cache_bs, int cache_ld, int cache_rows) {
+    const int half = Dh / 2, hq4 = half / 4;
+    const int per_row = (Hq + Hkv) * hq4 + Hkv * Dh / 4;
+    const int total = B * per_row;
+    for (int gi = blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += gridDim.x * blockDim.x) {
+        const int b = gi / per_row;
+        int rem = gi - b * per_row;
+        const float* xr = x + (size_t)b * ldx;
+        int p = pos[b];
+        const int prow = p < 0 ? 0 : (p >= cache_rows ? cache_rows - 1 : p);       // device-side positions are clamped (cache row and table row)
+        p = p < 0 ? 0 : (p >= tab_rows ? tab_rows - 1 : p);
+        _Float16* crow = cache + (size_t)b * (size_t)cache_bs + (size_t)prow * (size_t)cache_ld;
+        if (rem >= (Hq + Hkv) * hq4) {                                             // v: cast only
+            const int c = (rem - (Hq + Hkv) * hq4) * 4;
+            const sc_f4 v = *reinterpret_cast<const sc_f4*>(xr + (Hq + Hkv) * Dh + c);
+            *reinterpret_cast<sc_h4*>(crow + Hkv * Dh + c) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            continue;
+        }
+        const int h = rem / hq4, i0 = (rem - h * hq4) * 4;
+        const bool isq = h < Hq;
+        const float* t = (isq ? tab_q : tab_k) + (size_t)p * Dh;
+        const sc_f4 a = *reinterpret_cast<const sc_f4*>(xr + h * Dh + i0), bb = *reinterpret_cast<const sc_f4*>(xr + h * Dh + half + i0);
+        const sc_f4 cs = *reinterpret_cast<const sc_f4*>(t + i0), sn = *reinterpret_cast<const sc_f4*>(t + half + i0);
+        sc_h4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float ra = __builtin_fmaf(-bb[e], sn[e], a[e] * cs[e]), rb = __builtin_fmaf(a[e], sn[e], bb[e] * cs[e]);
+            asm volatile("" : "+v"(ra), "+v"(rb));                  // fp32 fma, THEN the fp16 rounding (see k_rope_f32in)
+            oa[e] = (_Float16)ra;
+            ob[e] = (_Float16)rb;
+        }
+        _Float16* o = isq ? q_out + (size_t)b * ldq + h * Dh : crow + (h - Hq) * Dh;
+        *reinterpret_cast<sc_h4*>(o + i0) = oa;
+        *reinterpret_cast<sc_h4*>(o + half + i0) = ob;
+    }
+}
+
 // out[b, y*g + x, d0..d0+7] = mean of in[b, (y*r + dy)*P + (x*r + dx), d0..d0+7] over the r x r window (fp32 accumulation)
 __global__ void k_avgpool_tokens(const _Float16* __restrict__ in, _Float16* __restrict__ out, int P, int D, int r, int g, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one thread = 8 channels of one output token
@@ -246,6 +289,21 @@ extern "C" int sc_rope_table_f32(float* tab, int max_pos, int Dh, float theta, f
     const int n = max_pos * (Dh / 2);
     hipLaunchKernelGGL(k_rope_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab, max_pos, Dh / 2, log2f(theta), scale);
     SC_CHECK_LAUNCH("sc_rope_table_f32");
+    return SC_OK;
+}
+
+extern "C" int sc_rope_qkv_rows_f16(const float* x, int ldx, const float* tab_q, const float* tab_k, int tab_rows, const int32_t* positions, int B, int q_heads,
+                                    int kv_heads, int Dh, void* q_out, int ldq, void* cache, int64_t cache_batch_stride, int cache_ld, int cache_rows, sc_stream_t stream) {
+    SC_REQUIRE(x && tab_q && tab_k && positions && q_out && cache, "sc_rope_qkv_rows_f16: null pointer argument");
+    SC_REQUIRE(B > 0 && q_heads > 0 && kv_heads > 0 && Dh > 0 && Dh % 8 == 0 && tab_rows > 0 && cache_rows > 0, "sc_rope_qkv_rows_f16: bad sizes (Dh %% 8 == 0)");
+    SC_REQUIRE(ldx >= (q_heads + 2 * kv_heads) * Dh && ldx % 4 == 0 && ldq >= q_heads * Dh && ldq % 4 == 0 && cache_ld >= 2 * kv_heads * Dh && cache_ld % 4 == 0 &&
+               cache_batch_stride % 4 == 0, "sc_rope_qkv_rows_f16: leading dimensions too small or not multiples of 4");
+    SC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(tab_q) | reinterpret_cast<uintptr_t>(tab_k)) & 15) == 0 &&
+               ((reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(cache)) & 7) == 0, "sc_rope_qkv_rows_f16: x / tables must be 16-byte aligned, outputs 8-byte");
+    const long total = (long)B * ((q_heads + kv_heads) * (Dh / 8) + kv_heads * Dh / 4);
+    hipLaunchKernelGGL(k_rope_qkv_rows, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, tab_q, tab_k, tab_rows,
+                       positions, B, q_heads, kv_heads, Dh, (_Float16*)q_out, ldq, (_Float16*)cache, cache_batch_stride, cache_ld, cache_rows);
+    SC_CHECK_LAUNCH("sc_rope_qkv_rows_f16");
     return SC_OK;
 }
 

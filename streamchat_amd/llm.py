@@ -91,6 +91,16 @@ class Qwen2Model:
     def embed_tokens(self, ids):
         return ops.gather_rows(ids.to(self.device).view(-1), self.embed)
 
+    def shared_view(self, max_seq=None):
+        """A second model over the SAME weight tensors with its own KV cache, activation buffers and scratch (round 5, session.py: the answer
+        whose tokens are being decoded and the next question's prefill each need a cache; the reference keeps two full replicas on two
+        GPUs, inference_streaming_longva_v2.py:696-720).  Nothing is copied."""
+        import copy
+        v = copy.copy(self)
+        v.cache, v.cache_len, v._buf_rows, v._b, v._f32_scratch, v._nsplit_prompt = None, 0, 0, None, None, None
+        v.max_seq = max_seq or self.max_seq
+        return v
+
     # ---- rotary tables (round 3): RoPE is applied to the fp32 projection sums and rounded ONCE; the query table carries the softmax
     # scale * log2 e, so q reaches sc_attention_f16 pre-scaled (SC_ATTN_Q_PRESCALED) - llm_ops.hip k_rope_table / gemm.hip rotary epilogue
     def rope_tabs(self, n_pos=None):
@@ -477,6 +487,7 @@ class BatchDecoder:
             lm.cache, lm.cache_len, lm.max_seq, lm._nsplit_prompt = saved
         # fp32 q | k | v sums of one step: owned here (the decode step is graph-captured; the model's shared scratch may be regrown by a later call)
         self._qkv32 = torch.empty((self.B, (c.heads + 2 * c.kv_heads) * c.head_dim), dtype=torch.float32, device=dev)
+        self._q16 = torch.empty((self.B, c.heads * c.head_dim), dtype=torch.float16, device=dev)
         self.logits = torch.stack(first_logits)                                  # [B, vocab] fp32
 
     def step(self, tokens):
@@ -485,20 +496,16 @@ class BatchDecoder:
         lm, c, B = self.lm, self.lm.cfg, self.B
         dq, dkv, Dh = c.heads * c.head_dim, c.kv_heads * c.head_dim, c.head_dim
         h = ops.gather_rows(tokens, lm.embed)
-        rows = self._row0 + self.len.to(torch.int64)
         kvlen = self.len + 1
         for l, L in enumerate(lm.L):
             x = ops.rmsnorm(h, L["ln1"], c.eps)
-            q = torch.empty((B, dq), dtype=torch.float16, device=h.device)
-            kv = torch.empty((B, 2 * dkv), dtype=torch.float16, device=h.device)
             # q | k | v in ONE projection launch over the fused weight (the same column sums as two launches), fp32 sums -> RoPE at each
-            # sequence's position -> one rounding (the numerics of Qwen2Model._qkv_rows)
+            # sequence's position -> one rounding (the numerics of Qwen2Model._qkv_rows) and the new K | V row appended to each sequence's
+            # cache, in ONE launch (round 5: was rope(q) + rope(k|v) + index_copy_)
             s32 = ops.gemm(x, L["wqkv"], L["bqkv"], out=self._qkv32, out_f32=True)
             tq, tk = self._rope_tabs
-            ops.rope_f32in(s32[:, :dq], tq, c.heads, Dh, q, 0, 0, self.len)
-            ops.rope_f32in(s32[:, dq:], tk, c.kv_heads, Dh, kv, dkv, 0, self.len)
             ck = self.cache[l]
-            ck.view(B * self.cap, -1).index_copy_(0, rows, kv)
+            q = ops.rope_qkv_rows(s32, tq, tk, self.len, c.heads, c.kv_heads, Dh, self._q16, ck)
             # the G query heads of a KV group as G query ROWS of that KV head (addressing only; q batch stride = dq)
             G = c.heads // c.kv_heads
             att = ops.attention(q.as_strided((B, G, Dh), (dq, Dh, 1)), ck[:, :, :dkv], ck[:, :, dkv:], c.kv_heads, c.kv_heads, Dh, Dh ** -0.5,

@@ -77,10 +77,16 @@ class _timed:
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch (caller-owned memory handed to the library; 256-byte aligned)."""
+    """Grow-only scratch per (device, current stream) (caller-owned memory handed to the library; 256-byte aligned).  Per STREAM since round 5:
+    two host threads driving two streams (session.py: the QA thread beside the reader / updater) must not hand the same scratch to kernels
+    that run at the same time; a buffer that is replaced stays alive until its stream has passed it (record_stream)."""
     d = torch.device(device)
-    key = d.index if d.index is not None else torch.cuda.current_device()
+    dev = d.index if d.index is not None else torch.cuda.current_device()
+    st = torch.cuda.current_stream(dev)
+    key = (dev, st.cuda_stream)
     buf = _ws_cache.get(key)
+    if buf is not None and buf.numel() < nbytes:
+        buf.record_stream(st)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
@@ -412,6 +418,23 @@ def rope_f32in(x32, tab, heads: int, Dh: int, out, plain_cols: int = 0, pos0: in
         check(_lib.load().sc_rope_f32in_f16(c_void_p(x2.data_ptr()), x2.stride(0), c_void_p(tab.data_ptr()), int(tab.shape[0]), ptr(pos), int(pos0), x2.shape[0], heads, Dh, plain_cols,
                                             c_void_p(o2.data_ptr()), o2.stride(0), stream_ptr(x32.device)), "sc_rope_f32in_f16")
     return out
+
+
+def rope_qkv_rows(x32, tab_q, tab_k, positions, q_heads: int, kv_heads: int, Dh: int, q_out, cache):
+    """Batched decode: x32 [B, (q_heads + 2 kv_heads) * Dh] fp32 (fused q|k|v projection + bias of one new token per sequence) -> q_out [B, q_heads * Dh]
+    fp16 (rotated, pre-scaled table) and row positions[b] of cache[b] ([B, cap, 2 * kv_heads * Dh]: rotated K | V).  One launch; the numbers of
+    rope_f32in on q and on k|v + index_copy_."""
+    _require_cuda(x32, tab_q, tab_k, positions, q_out, cache)
+    if x32.dtype != torch.float32 or q_out.dtype != torch.float16 or cache.dtype != torch.float16 or positions.dtype != torch.int32 or cache.dim() != 3:
+        raise StreamChatHipError("rope_qkv_rows: fp32 x, fp16 q_out / cache [B, cap, 2 * kv_heads * Dh], int32 positions")
+    if x32.stride(-1) != 1 or q_out.stride(-1) != 1 or cache.stride(-1) != 1 or tab_q.shape[0] != tab_k.shape[0] or not positions.is_contiguous():
+        raise StreamChatHipError("rope_qkv_rows: unit last strides, equal table lengths, contiguous positions")
+    from ctypes import c_void_p
+    with torch.cuda.device(x32.device):
+        check(_lib.load().sc_rope_qkv_rows_f16(c_void_p(x32.data_ptr()), x32.stride(0), c_void_p(tab_q.data_ptr()), c_void_p(tab_k.data_ptr()), int(tab_q.shape[0]),
+                                               ptr(positions), x32.shape[0], q_heads, kv_heads, Dh, c_void_p(q_out.data_ptr()), q_out.stride(0),
+                                               c_void_p(cache.data_ptr()), cache.stride(0), cache.stride(1), cache.shape[1], stream_ptr(x32.device)), "sc_rope_qkv_rows_f16")
+    return q_out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out=None):

@@ -1,0 +1,182 @@
+"""Reader / updater / QA concurrency on ONE GPU.
+
+The reference's intended on-line design runs three Python threads - `video_reader_thread_with_embedding`, `updating_memory_buffer` and the
+inference thread (previous_version/streaming_demo_llava_next_3.py:967-991) - and its batch entry point runs the same three stages one after the
+other per question (inference_streaming_longva_v2.py:845-905).  Here the stages of consecutive segments overlap where they stress different
+units of the chip:
+
+  MFMA side (matrix pipe, power-capped):  encode(i) -> memory update(i) -> retrieval + answer prefill(i)       host thread 1, stream A
+  HBM  side (weight / KV streaming):      answer decode(i), 3 ms per token at a 49 k context                   host thread 2, stream B
+
+decode(i) runs while thread 1 is already encoding, selecting and prefilling segment i + 1.  The two streams are CU-partitioned
+(`ops.masked_stream`: the persistent MFMA kernels own every register of the CUs they run on, so the two jobs cannot share a CU; decode
+keeps most of its rate on half of the CUs because it is bound by HBM, the MFMA side loses less than the CUs it gives up because the chip is
+power-capped - profiles/r05_*overlap*).  Two host threads, because a hipGraph replay queue is as long as the GPU work behind it: one thread
+enqueuing both jobs serialises them.
+
+Results do not depend on the mode: every kernel's arithmetic is independent of the CU count and of what runs beside it, each segment's
+RNG draws are seeded per segment, the memory tree is replaced (never mutated) by an update, and the answer being decoded owns its KV cache
+(`Qwen2Model.shared_view`, two caches used alternately).  `overlap=False` runs the same jobs in the same order on the current stream."""
+import queue
+import random
+import threading
+
+import numpy as np
+import torch
+
+from . import llm as LM, ops, streaming as S, utiles as U
+from .mm_utils import tokenizer_image_token
+
+IMAGE_TOKEN_INDEX = -200
+
+
+class _Worker(threading.Thread):
+    """FIFO of callables on one host thread; the first exception stops the worker and is re-raised by `drain()`."""
+
+    def __init__(self, name):
+        super().__init__(name=name, daemon=True)
+        self.q, self.exc = queue.Queue(), None
+        self.start()
+
+    def run(self):
+        while True:
+            fn = self.q.get()
+            if fn is None:
+                return
+            if self.exc is None:
+                try:
+                    fn()
+                except BaseException as e:          # noqa: BLE001 - handed to the caller's thread
+                    self.exc = e
+            self.q.task_done()
+
+    def submit(self, fn):
+        self.q.put(fn)
+
+    def drain(self):
+        self.q.join()
+        if self.exc is not None:
+            e, self.exc = self.exc, None
+            raise e
+
+    def close(self):
+        self.q.put(None)
+
+
+class StreamingSession:
+    """`submit(frames_u8, question)` per segment, `results()` at the end.  One record per segment: the frames kept as short-term memory, the
+    frames retrieved for the question, the context length, the first token and the decoded answer ids."""
+
+    def __init__(self, model, encoder, embedding_model, embedding_tokenizer, tokenizer, mem, summarizer, summarizer_tokenizer, *, overlap=True,
+                 decode_cus=128, max_new_tokens=512, conv_mode="qwen_1_5", max_context=53248, device=None, batch_captions=False):
+        self.model, self.encoder, self.colbert, self.colbert_tok, self.tok = model, encoder, embedding_model, embedding_tokenizer, tokenizer
+        self.mem, self.cap, self.cap_tok, self.batch_captions = dict(mem), summarizer, summarizer_tokenizer, batch_captions
+        self.overlap, self.max_new, self.conv_mode = bool(overlap), int(max_new_tokens), conv_mode
+        self.device = torch.device(device if device is not None else model.device)
+        lm, c = model.lm, model.lm.cfg
+        self.views = [lm.shared_view(max_context), lm.shared_view(max_context)]
+        for v in self.views:
+            v.reset_cache()
+        # ONE split-KV factor for every answer of the session (the serial and the overlapped run then merge their partials in the same grouping)
+        self.nsplit = LM.decode_nsplit(c.head_dim, max_context - self.max_new)
+        self.graphs = [LM.DecodeGraph(v, max_new_tokens=max(self.max_new, 16), nsplit=self.nsplit) for v in self.views]
+        for v, g in zip(self.views, self.graphs):      # captured here, on the caller's thread, before any worker exists
+            v.cache_len = 8
+            g.start(0)
+            g.capture()
+            v.cache_len = 0
+        torch.cuda.synchronize(self.device)
+        ncu = ops.device_info()["cu_count"]
+        if self.overlap:
+            dc = max(8, min(ncu - 8, int(decode_cus) // 8 * 8))
+            self.s_hbm, self.s_mfma = ops.masked_stream(0, dc, self.device), ops.masked_stream(dc, ncu - dc, self.device)
+            self.decode_cus = dc
+            self.w_mfma, self.w_hbm = _Worker("streamchat-reader-updater"), _Worker("streamchat-qa-decode")
+        else:
+            self.s_hbm = self.s_mfma = None
+            self.decode_cus = ncu
+        self.tree, self.search_cache = None, U.CaptionEmbeddingCache()
+        self.records, self.banks, self.n = [], [], 0
+        self.slot_free = [threading.Event(), threading.Event()]
+        for e in self.slot_free:
+            e.set()
+
+    # ---- the two jobs of a segment ----
+    def _ingest_and_prefill(self, i, frames, question):
+        rec = self.records[i]
+        feats = self.encoder.encode_frames_u8(frames)                                   # reader: [n, 576, D] fp16, a bank of its own per segment
+        self.banks.append(feats)
+        bank = [feats[j:j + 1] for j in range(feats.shape[0])]
+        torch.manual_seed(i); random.seed(i)                                            # the updater's host draws (k-means initial rows / reseeds), per segment
+        self.tree, short = S.updating_memory_buffer(bank, self.tree, self.cap, self.cap_tok, True, rng=np.random.RandomState(i),
+                                                    batch_captions=self.batch_captions, **self.mem)
+        tree = self.tree                                                                # (a new list per update: the QA of this segment keeps this one)
+        row = feats[0].numel()
+        rec["short"] = [int((t.storage_offset() - feats.storage_offset()) // row) for t in short]
+        # QA, first half: retrieval, prompt, splice, prefill into this segment's cache
+        short_emb = U.cat_frames(short).view(-1, short[0].shape[-1])
+        path, texts = U.fast_search_tree_multi_modal_with_embedding(tree, question, short_emb, self.colbert, self.colbert_tok, cache=self.search_cache)
+        rec["path_text"], rec["retrieved_rows"] = list(texts), [int(t.shape[0]) for t in path]
+        rec["retrieved_crc"] = [int(t.reshape(-1)[:64].float().sum().item() * 1024) for t in path]
+        qs = S.build_answer_prompt(question, texts[-1] if texts else None, None, getattr(self.model.config, "mm_use_im_start_end", False))
+        conv = S.conv_templates[self.conv_mode].copy()
+        conv.append_message(conv.roles[0], qs)
+        conv.append_message(conv.roles[1], None)
+        ids = tokenizer_image_token(conv.get_prompt(), self.tok, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0)
+        pieces = [short_emb] + [t.reshape(-1, t.shape[-1]) for t in path]
+        _, _, _, _, embeds, _ = self.model.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, [pieces], ["video"])
+        slot = i % 2
+        self.slot_free[slot].wait()                                                     # the answer that used this cache two segments ago is out
+        self.slot_free[slot].clear()
+        lmv = self.views[slot]
+        lmv.cache_len = 0
+        if embeds.shape[1] + self.max_new > lmv.max_seq:
+            raise ValueError(f"session: context {embeds.shape[1]} + {self.max_new} new tokens exceeds max_context {lmv.max_seq}")
+        logits = lmv.forward(embeds[0])
+        first = int(torch.argmax(logits).item())                                        # greedy (host sync of THIS stream only)
+        rec["context"], rec["first_token"] = int(embeds.shape[1]), first
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return slot, first, ev, embeds                                                  # (embeds kept alive until the decode has been enqueued)
+
+    def _decode(self, i, slot, first, ev, keep):
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        g = self.graphs[slot]
+        g.start(first)
+        self.records[i]["tokens"] = [first] + g.run(self.max_new - 1)
+        self.slot_free[slot].set()
+        del keep
+
+    # ---- scheduling ----
+    def submit(self, frames_u8, question):
+        i = self.n
+        self.n += 1
+        self.records.append(dict(segment=i, question=question))
+        if not self.overlap:
+            with torch.no_grad():
+                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question)
+                self._decode(i, slot, first, ev, keep)
+            return i
+
+        def mfma_job():
+            with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma):
+                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question)
+
+            def hbm_job():
+                with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_hbm):
+                    self._decode(i, slot, first, ev, keep)
+            self.w_hbm.submit(hbm_job)
+        self.w_mfma.submit(mfma_job)
+        return i
+
+    def results(self):
+        """waits for everything submitted so far"""
+        if self.overlap:
+            self.w_mfma.drain()
+            self.w_hbm.drain()
+        torch.cuda.synchronize(self.device)
+        return self.records
+
+    def close(self):
+        if self.overlap:
+            self.w_mfma.close(); self.w_hbm.close()
