@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU-baseline slice (SURVEY 8(d): 64 = C1's encode)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
+    ap.add_argument("--session", type=int, default=3, metavar="SEGMENTS",
+                    help="AFTER the headline measurement (C3, one GPU): a stream of SEGMENTS segments with a --decode-tokens answer each, serial vs "
+                         "reader/updater || QA-decode overlapped on two CU partitions (streamchat_amd/session.py); reported as `session`; 0 = off")
+    ap.add_argument("--session-decode-cus", type=int, nargs="*", default=[112, 128], help="CUs of the decode partition(s) to try in --session")
     ap.add_argument("--with-captions", type=int, nargs="?", const=2, default=1, metavar="STEPS",
                     help="AFTER the headline measurement: STEPS more steps (default 1; 0 = off) in which the chunk captioner is the HIP 7B model itself "
                          "(one 23 k-token prefill + 128 new tokens per 40-frame chunk through llm.BatchDecoder, reference utiles.py:539-559), "
@@ -121,6 +125,45 @@ def measure_product(pipe, k, n_total):
                             frac=round(r["decode_bytes"] / max(r["decode_s"], 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
                             tokens_per_s_aggregate=round(r["new_tokens"] / max(r["decode_s"], 1e-9), 1), ms_per_decode_step=round(r["decode_s"] / max(r["decode_steps"], 1) * 1e3, 2),
                             decode_steps_per_step=r["decode_steps"] // k, split_kv=r.get("nsplit")))
+
+
+def measure_session(pipe, n_frames, segments, tokens, decode_cus_list):
+    """BASELINE configs[2] as a STREAM of segments (reader / updater / QA): `segments` segments of `n_frames` frames, one question
+    and one `tokens`-token greedy answer each - the same jobs once one after the other on the whole chip (the reference's batch entry point,
+    inference_streaming_longva_v2.py:845-905) and once with the answer decode of segment i overlapped with the encode / update / prefill of
+    segment i + 1 on two CU partitions and two host threads (streamchat_amd/session.py).  Frames per second over the whole session, and
+    whether the two runs retrieved the same frames and produced the same tokens."""
+    from streamchat_amd import session as SS
+    dev = pipe.device
+    segs = [torch.from_numpy(synthetic.frame_stream(n_frames, seed=1234, start=i * n_frames)).to(dev) for i in range(segments)]
+    qs = [f"segment {i}: where did I leave the {synthetic.VOCAB[(7 * i) % len(synthetic.VOCAB)]} and what was on the kitchen table" for i in range(segments)]
+
+    def run(overlap, dc):
+        s = SS.StreamingSession(pipe.model, pipe.enc, pipe.colbert, pipe.tok, pipe.llm_tok, MEM, synthetic.SyntheticCaptioner(dev), synthetic.SyntheticTokenizer(),
+                                overlap=overlap, decode_cus=dc, max_new_tokens=tokens, max_context=pipe.model.lm.max_seq)
+        s.submit(segs[0], qs[0]); s.results()                    # warm-up segment (allocations), then the same session object starts over
+        s.tree, s.search_cache, s.records, s.banks, s.n = None, U.CaptionEmbeddingCache(), [], [], 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for f, q in zip(segs, qs):
+            s.submit(f, q, new_video=True)                       # every segment is a C3 stream of its own (context ~49 k), as configs[2] describes it
+        rec = s.results()
+        dt = time.perf_counter() - t0
+        s.close()
+        keep = [{k: r[k] for k in ("short", "path_text", "retrieved_rows", "retrieved_crc", "context", "first_token", "tokens")} for r in rec]
+        del s
+        torch.cuda.empty_cache()
+        return dt, keep
+    t_serial, ref = run(False, 0)
+    out = dict(what="C3 with its 512-token answer as a stream of segments: serial (one stream, whole chip) vs reader/updater || QA-decode on two CU partitions and two host threads",
+               segments=segments, frames_per_segment=n_frames, answer_tokens=tokens, context=[r["context"] for r in ref],
+               serial_s=round(t_serial, 3), serial_frames_per_s=round(segments * n_frames / t_serial, 2), overlapped=[])
+    for dc in decode_cus_list:
+        t, rec = run(True, dc)
+        out["overlapped"].append(dict(decode_cus=dc, s=round(t, 3), frames_per_s=round(segments * n_frames / t, 2), speedup=round(t_serial / t, 3), identical_to_serial=rec == ref))
+    best = max(out["overlapped"], key=lambda r: r["frames_per_s"])
+    out["overlapped_frames_per_s"], out["best_decode_cus"], out["speedup"] = best["frames_per_s"], best["decode_cus"], best["speedup"]
+    out["identical_to_serial"] = all(r["identical_to_serial"] for r in out["overlapped"])
+    return out
 
 
 class Pipeline:
@@ -714,12 +757,19 @@ def main():
         gb_tok = 14.1 + 2 * 28 * 4 * 128 * ctxlen * 2 / 1e9       # fp16 weights incl. lm_head + KV bytes per token
         out["decode_tokens_per_s"] = round(rate, 2)
         out["decode_tokens"] = a.decode_tokens
-        # BASELINE.json configs[2] in full: the step of the headline metric PLUS the 512-token answer (serial: a CU-partitioned overlap of the
-        # answer decode with the next segment's encode / prefill was built and measured slower, profiles/r05_run_i_overlap_cu_partition.jsonl)
+        # BASELINE.json configs[2] in full: the step of the headline metric PLUS the 512-token answer, one after the other (the overlapped stream of
+        # segments is the `session` object below)
         out["c3_with_decode_frames_per_s"] = round(n_total / (ms_step / 1e3 + a.decode_tokens / rate), 2)
         out["c3_with_decode_ms_per_step"] = round(ms_step + a.decode_tokens / rate * 1e3, 1)
         out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv / k_decode_qkv + k_attn_decode (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
                                                 unit="GB/s", frac=round(rate * gb_tok / HBM_PEAK_GBS, 4), gb_per_token=round(gb_tok, 2))
+    if a.session > 0 and full and world == 1 and config == "C3" and a.decode_tokens > 0:
+        try:
+            out["session"] = measure_session(pipe, n_total, a.session, a.decode_tokens, a.session_decode_cus)
+        except Exception as e:                                   # a side measurement must never take the headline line with it
+            out["session"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        finally:
+            torch.cuda.empty_cache()
     if a.with_captions and full and world == 1 and config == "C3":
         # what the metric leaves out (SURVEY 8(f).1 "the true wall-clock dominator"), measured once on this code: the same step with the HIP
         # 7B model as the chunk captioner.  Separate object; `value` above is the headline metric and does not contain it.

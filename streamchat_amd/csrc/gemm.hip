@@ -1264,6 +1264,152 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_x(const _Float16* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the skinny GEMM with BOTH operands staged through per-wave LDS rings by LDS-DMA (k_gemm_skinny_l).
+// What bounds the register-operand kernels above is not HBM and not occupancy (8 / 16 waves per strip change nothing,
+// profiles/r05_run_k_*) but the CU's address path: the MFMA A / B operand layout makes lane (rl, g) read 16 bytes of ROW rl at k-chunk g, so
+// the 16 lanes of a quarter-wave touch 16 different rows - every `global_load_dwordx4` is 64 separate cache-line lookups of 16 bytes
+// each, against 8 for a coalesced 1 KiB.  At one line per clock that IS the measured time of the 3584-row projections of the batched
+// decode: o 84 instructions x 64 lines x 4 waves = 21.5 k clocks = 10.2 us of 12.2; q|k|v the same in two rounds of workgroups (20.6);
+// down 444 x 64 x 4 = 113.7 k clocks = 54 us (50.7 measured).  Here every global access is an LDS-DMA instruction that fetches four rows
+// x 256 contiguous bytes (8 lines), and the operand fragments come out of LDS with conflict-free ds_read_b128 (rows of 256 B, the
+// 16-byte piece index XORed with the row on the SOURCE side - the layout of k_attn_decode's K ring):
+//   * one workgroup = 4 waves = the 4 K-quarters of a strip of 16 weight rows, persistent over a contiguous range of strips;
+//   * per wave a ring of PD stages; a stage = 128 k of its K-quarter: W 16 rows x 256 B (4 DMA instructions) + x MG*16 rows x 256 B
+//     (4 MG instructions; rows >= M lie outside the buffer extent: zeros, no traffic); the ring runs on across strip boundaries;
+//   * no block barrier in the stream: every wait is a hand-counted `s_waitcnt vmcnt` on the wave's own DMA queue, every LDS read inline
+//     asm (behind builtin LDS reads hipcc drains the DMA queue with vmcnt(0): see attention_decode.hip);
+//   * per strip ONE pair of barriers (without vmcnt(0)) around the exchange of the partial tiles; wave 0 applies the epilogue.  What the
+//     epilogue adds (bias, residual tile) reaches wave 0 by two more DMA instructions issued with the strip's first stage - an ordinary
+//     load there would make hipcc drain wave 0's queue once per strip;
+//   * MFMA operands, k order per accumulator and the cross-wave sum are those of k_gemm_skinny: bit-identical results.
+// K % 512 == 0 (K / 4 in whole stages), M <= 16 MG, lda / ldr multiples of 8.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI, bool OUT_F32, int MG, int PD>
+__global__ __launch_bounds__(256) void k_gemm_skinny_l(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                       const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                       void* __restrict__ Cout, int ldc, int M, int N, int K, int strips_q, int strips_r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WST = 4096, XST = MG * 4096, STB = WST + XST, NOPS = 4 + 4 * MG;
+    constexpr int CNT = (PD - 1) * NOPS;                       // DMA ops younger than the stage being waited for
+    static_assert(PD >= 2 && CNT < 64, "vmcnt is a 6-bit counter");
+    constexpr int RING = 4 * PD * STB, RED = 3 * MG * 4 * 64 * 4, EB = 2048;      // rings | partial tiles | 2 x {residual tile 1 KiB, bias 1 KiB}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int s_lo = b * strips_q + min(b, strips_r), s_hi = s_lo + strips_q + (b < strips_r ? 1 : 0);
+    if (s_lo >= s_hi) return;
+    const int kq = K >> 2, k_lo = wave * kq, nst = kq >> 7;
+    const int total = (s_hi - s_lo) * nst;
+    char* ring = smem + wave * (PD * STB);
+    const unsigned ring_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (PD * STB));
+    float* red = reinterpret_cast<float*>(smem + RING);        // [3][MG][4][64]
+    char* ebuf = smem + RING + RED;                            // [2][R tile | bias]
+    // per-lane source offsets of a stage's granules: granule j lands lane-linear = row j*4 + (lane >> 4), 16-byte slot lane & 15
+    unsigned w_vo[4], x_vo[4 * MG];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = j * 4 + (lane >> 4); w_vo[j] = ((unsigned)r * (unsigned)K + (unsigned)(((lane & 15) ^ (r & 15)) * 8)) * 2u; }
+#pragma unroll
+    for (int j = 0; j < 4 * MG; ++j) { const int r = j * 4 + (lane >> 4); x_vo[j] = ((unsigned)r * (unsigned)lda + (unsigned)(((lane & 15) ^ (r & 15)) * 8)) * 2u; }
+    const unsigned w_ext = (15u * (unsigned)K + 128u) * 2u, x_ext = ((unsigned)(M - 1) * (unsigned)lda + 128u) * 2u;
+    unsigned f_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f_off[t] = (unsigned)(rl * 256 + (((t * 4 + g) ^ rl) << 4));
+    // running (strip, stage) of the NEXT stage to request
+    int is_strip = s_lo, is_st = 0, iq = 0;
+    auto issue = [&]() {
+        const bool live = iq < total;
+        char* dst = ring + (iq % PD) * STB;
+        if (wave == 0 && is_st == 0) {                          // what this strip's epilogue adds, into the E buffer of the strip's parity
+            char* e = ebuf + ((is_strip - s_lo) & 1) * EB;
+            const int n0 = is_strip * 16;
+            lds_load16(R ? R + n0 : W, (live && R) ? ((unsigned)(M - 1) * (unsigned)ldr + 16u) * 2u : 0u, e, ((unsigned)(lane >> 1) * (unsigned)ldr + (unsigned)(lane & 1) * 8u) * 2u, 0u);
+            lds_load16(bias ? bias + n0 : W, (live && bias) ? 32u : 0u, e + 1024, (unsigned)lane * 16u, 0u);
+        }
+        const _Float16* wb = W + (size_t)is_strip * (size_t)(16 * K) + k_lo + is_st * 128;
+        const _Float16* xb = A + k_lo + is_st * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_load16(wb, live ? w_ext : 0u, dst + j * 1024, w_vo[j], 0u);
+#pragma unroll
+        for (int j = 0; j < 4 * MG; ++j) lds_load16(xb, live ? x_ext : 0u, dst + WST + j * 1024, x_vo[j], 0u);
+        ++iq;
+        if (++is_st == nst) { is_st = 0; if (live) ++is_strip; }
+    };
+    sc_f4 acc[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < PD; ++u) issue();
+    int st = 0, strip = s_lo;
+    for (int q = 0; q < total; ++q) {
+        const unsigned sa = ring_lds + (unsigned)((q % PD) * STB);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+        sc_u4 wf[4], xf[MG][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(sa + f_off[t]));
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[mg][t]) : "v"(sa + f_off[t]), "n"(WST + mg * 4096));
+        }
+        if constexpr (MG == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]),
+                                                  "+v"(xf[1][0]), "+v"(xf[1][1]), "+v"(xf[1][2]), "+v"(xf[1][3]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]) :: "memory");
+        issue();                                               // this stage's slot is free: its fragments are in registers
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+                acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, wf[t]), __builtin_bit_cast(sc_h8, xf[mg][t]), acc[mg], 0, 0, 0);
+        if (++st < nst) continue;
+        // ---- strip done: exchange the partial tiles (barrier pair without vmcnt(0): the DMA ring stays in flight), wave 0 stores ----
+        st = 0;
+        asm volatile("s_barrier" ::: "memory");                // wave 0 has read the previous strip's partials
+        if (wave > 0) {
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave - 1) * MG + mg) * 4 + r) * 64 + lane] = acc[mg][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave == 0) {
+            const int n = strip * 16 + g * 4;
+            const char* e = ebuf + ((strip - s_lo) & 1) * EB;   // landed: issued before this strip's first stage, which has been waited for
+            const sc_h4 bv = *reinterpret_cast<const sc_h4*>(e + 1024 + g * 8);
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[mg][r];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) t += red[((w * MG + mg) * 4 + r) * 64 + lane];
+                    v[r] = t + (bias ? (float)bv[r] : 0.f);
+                }
+                const int m = mg * 16 + rl;
+                if (m >= M) continue;
+                if (EPI == SC_EPI_SWIGLU) {
+                    const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[2], o1 = v[1] / (1.0f + __expf(-v[1])) * v[3];
+                    const sc_h2 o = {(_Float16)o0, (_Float16)o1};
+                    *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epi_apply(v[r], EPI);
+                    if (R) { const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(e + m * 32 + g * 8); for (int r = 0; r < 4; ++r) v[r] += (float)r4[r]; }
+                    if (OUT_F32) *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+                    else *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                }
+            }
+        }
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+        ++strip;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may be in flight when the workgroup ends (hazard 3 of k_gemm_fat)
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
@@ -1276,6 +1422,30 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
     if (force == 0 && M <= 32 && K % 128 == 0 && a_grp == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0)) {      // few rows: stream W once
         const dim3 grid((unsigned)(N / 16)), block(256);
+        // both operands through LDS rings (k_gemm_skinny_l): K in whole 512-element quarters-of-stages; SC_SKINNY_LDS=0 pins the register-operand kernels
+        static int lds_on = -1;
+        if (lds_on < 0) { const char* e = getenv("SC_SKINNY_LDS"), *gnr = getenv("SC_SKINNY_GENERIC"); lds_on = ((e && e[0] == '0') || (gnr && gnr[0] == '1')) ? 0 : 1; }
+        // (K >= 2048: a strip has at least PD stages per wave, so the epilogue buffer of strip s + 2 is requested after strip s has been stored)
+        // FEW strips only (N / 16 below two per CU: o, down, q|k|v, kv of the batched decode, the text encoders' K = 4096 projections).  Measured
+        // at M = 26, same box, us per launch LDS / register operands (profiles/r05_run_o_skinny_lds.md): q 7.9 / 11.8, kv 6.9 / 11.1, o 8.0 / 12.1,
+        // q|k|v 11.5 / 20.5, down 38.8 / 50.6 - but gate/up 67.4 / 59.6 and lm_head 268 / 231: with many strips per workgroup the x-resident
+        // register kernel (k_gemm_skinny_x) reads x once per WORKGROUP, this one once per strip (543 MB of x through LDS for 271 MB of weights)
+        static int n_cu_l[16] = {};
+        if (n_cu_l[dev] == 0) { int n = 0; n_cu_l[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+        if constexpr (EPI == SC_EPI_NONE || EPI == SC_EPI_SWIGLU) if (lds_on && N / 16 < 2 * n_cu_l[dev] && K % 512 == 0 && K >= 2048 && lda % 8 == 0 && (!R || ldr % 8 == 0) &&
+                                                                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
+            const int strips = N / 16, cus = sc_launch_cu_count(n_cu_l[dev], s), gx = strips < cus ? strips : cus;
+            static bool attr_done[16][8] = {};
+#define SC_LSL(F32, MGV, PDV, SLOT) do { constexpr int LDSB = 4 * PDV * (4096 + MGV * 4096) + 3 * MGV * 4 * 64 * 4 + 2 * 2048;                                   \
+                if (!attr_done[dev][SLOT]) { (void)hipFuncSetAttribute((const void*)k_gemm_skinny_l<EPI, F32, MGV, PDV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done[dev][SLOT] = true; } \
+                hipLaunchKernelGGL((k_gemm_skinny_l<EPI, F32, MGV, PDV>), dim3((unsigned)gx), block, LDSB, s, (const _Float16*)A, lda, (const _Float16*)W,        \
+                                   (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K, strips / gx, strips % gx); } while (0)
+            if (M <= 16) { if (out_f32) SC_LSL(true, 1, 4, 0); else SC_LSL(false, 1, 4, 1); }
+            else { if (out_f32) SC_LSL(true, 2, 3, 2); else SC_LSL(false, 2, 3, 3); }
+#undef SC_LSL
+            SC_CHECK_LAUNCH("sc_gemm_f16");
+            return SC_OK;
+        }
         static int unrolled = -1;                 // SC_SKINNY_GENERIC=1 pins the run-time-loop kernel (A/B runs, bit-identity test)
         if (unrolled < 0) { const char* e = getenv("SC_SKINNY_GENERIC"); unrolled = (e && e[0] == '1') ? 0 : 1; }
         if constexpr (EPI == SC_EPI_NONE || EPI == SC_EPI_SWIGLU) if (unrolled && (K == 3584 || K == 18944)) {

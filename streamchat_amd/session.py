@@ -102,8 +102,10 @@ class StreamingSession:
             e.set()
 
     # ---- the two jobs of a segment ----
-    def _ingest_and_prefill(self, i, frames, question):
+    def _ingest_and_prefill(self, i, frames, question, new_video=False):
         rec = self.records[i]
+        if new_video:                                                                   # the reference starts every video with an empty memory (:845-860)
+            self.tree, self.search_cache = None, U.CaptionEmbeddingCache()
         feats = self.encoder.encode_frames_u8(frames)                                   # reader: [n, 576, D] fp16, a bank of its own per segment
         self.banks.append(feats)
         bank = [feats[j:j + 1] for j in range(feats.shape[0])]
@@ -148,19 +150,20 @@ class StreamingSession:
         del keep
 
     # ---- scheduling ----
-    def submit(self, frames_u8, question):
+    def submit(self, frames_u8, question, new_video=False):
+        """one segment: its frames (uint8 [n, H, W, 3] on the device) and the question asked at its end.  `new_video`: forget the memory tree first."""
         i = self.n
         self.n += 1
         self.records.append(dict(segment=i, question=question))
         if not self.overlap:
             with torch.no_grad():
-                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question)
+                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
                 self._decode(i, slot, first, ev, keep)
             return i
 
         def mfma_job():
             with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma):
-                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question)
+                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
 
             def hbm_job():
                 with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_hbm):

@@ -1,0 +1,68 @@
+"""GPU: session.StreamingSession - the reader / updater thread and the QA-decode thread on two CU partitions (reference
+previous_version/streaming_demo_llava_next_3.py:967-991) must produce exactly what the same jobs produce one after the other on one stream:
+short-memory frames, retrieved nodes, context lengths, first tokens and every decoded token id."""
+import numpy as np
+import pytest
+import torch
+
+from streamchat_amd import llm as LM, ops, session as SS, synthetic, text as T, vision as V
+from tests import _composed as TC
+
+pytestmark = pytest.mark.gpu
+MEM = dict(short_window=20, remember_window=5, tau=5, chunk_size=8, num_clusters=3, interval=3)
+
+
+def _build(dev):
+    cfg = V.CLIPVisionConfigLite(hidden=128, layers=2, heads=2, intermediate=256, patch=14, image_size=56)
+    enc = V.FrameEncoder(V.CLIPVisionTower(V.random_clip_state_dict(cfg, seed=0, device=dev, std=0.08), cfg, device=dev),
+                         V.MMProjector(V.random_projector_state_dict(128, 256, seed=1, device=dev, std=0.08), device=dev), micro_batch=16)
+    qc = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=4, kv_heads=2, intermediate=512, vocab=1024)
+    model = LM.LlavaQwenForCausalLM(LM.Qwen2Model(LM.random_qwen2_state_dict(qc, seed=4, device=dev, std=0.05), qc, device=dev, max_seq=2048), enc)
+    bc = T.BertConfigLite(hidden=128, layers=2, heads=4, intermediate=256, vocab=2048, max_pos=128)
+    bert = T.BertEncoder(T.random_bert_state_dict(bc, seed=2, device=dev, std=0.05), bc, device=dev)
+    return enc, model, bert
+
+
+class _Tok(synthetic.SyntheticTokenizer):
+    def __call__(self, text, **kw):
+        r = super().__call__(text, **kw)
+        r.input_ids = [t % 1000 + 5 for t in r.input_ids]          # into the tiny vocabulary
+        return r
+
+
+def _run(overlap, segs, questions, n_new):
+    dev = torch.device("cuda:0")
+    enc, model, bert = _build(dev)
+    s = SS.StreamingSession(model, enc, bert, T.HashTokenizer(vocab=2048, max_len=64), _Tok(), MEM, TC.PositionCaptioner(dev), synthetic.SyntheticTokenizer(),
+                            overlap=overlap, decode_cus=96, max_new_tokens=n_new, max_context=2048)
+    for f, q in zip(segs, questions):
+        s.submit(f, q)
+    out = s.results()
+    s.close()
+    return out
+
+
+def test_overlapped_session_equals_serial_session():
+    dev = torch.device("cuda:0")
+    u8 = torch.from_numpy(TC.crossfade_stream(4 * 40, seed=77, period=8, h=56, w=56)).to(dev)
+    segs = [u8[i * 40:(i + 1) * 40] for i in range(4)]
+    questions = [f"segment {i}: " + " ".join(synthetic.caption(i + 1).split()[2:14]) for i in range(4)]
+    a = _run(False, segs, questions, 24)
+    b = _run(True, segs, questions, 24)
+    assert len(a) == len(b) == 4
+    for ra, rb in zip(a, b):
+        for k in ("short", "path_text", "retrieved_rows", "retrieved_crc", "context", "first_token", "tokens"):
+            assert ra[k] == rb[k], (ra["segment"], k, ra[k], rb[k])
+        assert len(ra["tokens"]) == 24 and len(ra["short"]) == 5
+    assert any(r["retrieved_rows"] for r in a) and a[1]["context"] > 16 * 5           # something was retrieved and spliced
+    print("\n[session] 4 segments x 40 frames, 24 tokens each: overlapped == serial;", [r["context"] for r in a], a[-1]["tokens"][:8])
+
+
+def test_worker_reraises_on_the_callers_thread():
+    w = SS._Worker("t")
+    w.submit(lambda: (_ for _ in ()).throw(ValueError("boom")))
+    with pytest.raises(ValueError, match="boom"):
+        w.drain()
+    w.submit(lambda: None)
+    w.drain()
+    w.close()
