@@ -57,10 +57,10 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU-baseline slice (SURVEY 8(d): 64 = C1's encode)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
-    ap.add_argument("--session", type=int, default=3, metavar="SEGMENTS",
+    ap.add_argument("--session", type=int, default=4, metavar="SEGMENTS",
                     help="AFTER the headline measurement (C3, one GPU): a stream of SEGMENTS segments with a --decode-tokens answer each, serial vs "
                          "reader/updater || QA-decode overlapped on two CU partitions (streamchat_amd/session.py); reported as `session`; 0 = off")
-    ap.add_argument("--session-decode-cus", type=int, nargs="*", default=[112, 128], help="CUs of the decode partition(s) to try in --session")
+    ap.add_argument("--session-decode-cus", type=int, nargs="*", default=[128], help="CUs of the decode partition(s) to try in --session (multiples of 32)")
     ap.add_argument("--with-captions", type=int, nargs="?", const=2, default=1, metavar="STEPS",
                     help="AFTER the headline measurement: STEPS more steps (default 1; 0 = off) in which the chunk captioner is the HIP 7B model itself "
                          "(one 23 k-token prefill + 128 new tokens per 40-frame chunk through llm.BatchDecoder, reference utiles.py:539-559), "

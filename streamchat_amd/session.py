@@ -88,10 +88,16 @@ class StreamingSession:
         torch.cuda.synchronize(self.device)
         ncu = ops.device_info()["cu_count"]
         if self.overlap:
-            dc = max(8, min(ncu - 8, int(decode_cus) // 8 * 8))
+            # (multiples of 32 CUs: the mask bits go round-robin over 8 XCDs x 4 shader engines, and a partition that leaves the engines of an XCD
+            #  unequal is paced by its smallest one - 112 / 144 CUs measured 25 - 35 % SLOWER than 96 / 128, profiles/r05_run_p_*)
+            dc = max(32, min(ncu - 32, int(decode_cus) // 32 * 32))
             self.s_hbm, self.s_mfma = ops.masked_stream(0, dc, self.device), ops.masked_stream(dc, ncu - dc, self.device)
+            # a job that starts while the other side has nothing queued takes the whole chip (the first segment's encode, the last answer's decode)
+            self.s_hbm_full, self.s_mfma_full = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
             self.decode_cus = dc
             self.w_mfma, self.w_hbm = _Worker("streamchat-reader-updater"), _Worker("streamchat-qa-decode")
+            self._pending = {"mfma": 0, "hbm": 0}
+            self._lock = threading.Lock()
         else:
             self.s_hbm = self.s_mfma = None
             self.decode_cus = ncu
@@ -161,14 +167,31 @@ class StreamingSession:
                 self._decode(i, slot, first, ev, keep)
             return i
 
+        def count(side, d):
+            with self._lock:
+                self._pending[side] += d
+                return self._pending
+
         def mfma_job():
-            with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma):
-                slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
+            shared = self._pending["hbm"] > 0                      # an answer is being decoded (or queued): stay on the MFMA partition
+            self.records[i]["mfma_partitioned"] = shared
+            try:
+                with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma if shared else self.s_mfma_full):
+                    slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
+            finally:
+                count("mfma", -1)
 
             def hbm_job():
-                with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_hbm):
-                    self._decode(i, slot, first, ev, keep)
+                shared = self._pending["mfma"] > 0
+                self.records[i]["decode_partitioned"] = shared
+                try:
+                    with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_hbm if shared else self.s_hbm_full):
+                        self._decode(i, slot, first, ev, keep)
+                finally:
+                    count("hbm", -1)
+            count("hbm", +1)
             self.w_hbm.submit(hbm_job)
+        count("mfma", +1)
         self.w_mfma.submit(mfma_job)
         return i
 
