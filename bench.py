@@ -41,7 +41,7 @@ MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+TRAFFIC_PROFILE = "profiles/r05_pmc_traffic.json"       # rocprofv3 --pmc passes of this command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
 
 
 def parse():

@@ -131,3 +131,31 @@ def test_attention_with_prescaled_queries(B, Sq, Skv, Hq, Hkv, Dh, causal, ns):
     out = ops.attention(qp, k, v, Hq, Hkv, Dh, 123.0, causal, nsplit=ns, q_prescaled=True)          # (scale is ignored in this mode)
     ref = _attn_ref(qp.float(), k, v, Hq, Hkv, Dh, 1.0 / ops.LOG2E, causal)
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_rope_qkv_rows_equals_rope_f32in_twice_plus_scatter():
+    """ABI 6 `sc_rope_qkv_rows_f16` (the batched decode step's rotary + KV append in ONE launch) is bit for bit what the three launches it
+    replaced produce: sc_rope_f32in_f16 on the q columns (scaled table), on the k|v columns (plain table, V cast), and a row scatter into each
+    sequence's cache at its own position - positions differ per sequence, the other cache rows stay untouched, out-of-range positions clamp."""
+    import torch
+    from streamchat_amd import ops
+    torch.manual_seed(3)
+    B, Hq, Hkv, Dh, cap = 5, 28, 4, 128, 40
+    dq, dkv = Hq * Dh, Hkv * Dh
+    x = torch.randn(B, dq + 2 * dkv, device="cuda") * 3
+    tq, tk = ops.rope_table(64, Dh, 1e6, Dh ** -0.5 * ops.LOG2E, "cuda"), ops.rope_table(64, Dh, 1e6, 1.0, "cuda")
+    pos = torch.tensor([0, 7, 39, 12, 3], dtype=torch.int32, device="cuda")
+    cache = torch.full((B, cap, 2 * dkv), 7.0, dtype=torch.float16, device="cuda")
+    q = torch.empty((B, dq), dtype=torch.float16, device="cuda")
+    ops.rope_qkv_rows(x, tq, tk, pos, Hq, Hkv, Dh, q, cache)
+    q_ref = ops.rope_f32in(x[:, :dq], tq, Hq, Dh, torch.empty_like(q), 0, 0, pos)
+    kv_ref = ops.rope_f32in(x[:, dq:], tk, Hkv, Dh, torch.empty((B, 2 * dkv), dtype=torch.float16, device="cuda"), dkv, 0, pos)
+    assert torch.equal(q.view(torch.int16), q_ref.view(torch.int16))
+    want = torch.full_like(cache, 7.0)
+    for b in range(B):
+        want[b, int(pos[b])] = kv_ref[b]
+    assert torch.equal(cache.view(torch.int16), want.view(torch.int16))
+    # strided cache view (a slice of a wider buffer) and a position past the cache: clamped to the last row, nothing written outside
+    wide = torch.zeros((B, cap, 2 * dkv + 64), dtype=torch.float16, device="cuda")
+    ops.rope_qkv_rows(x, tq, tk, torch.tensor([1, 2, 3, 4, 1000], dtype=torch.int32, device="cuda"), Hq, Hkv, Dh, q, wide[:, :, :2 * dkv])
+    assert float(wide[:, :, 2 * dkv:].abs().max()) == 0.0 and float(wide[4, cap - 1, :dkv].abs().max()) > 0
