@@ -169,6 +169,30 @@ def test_batched_greedy_decode_equals_one_by_one():
         assert got == (ref[:ref.index(eos) + 1] if eos in ref else ref)
 
 
+def test_batch_decoder_leaves_the_models_prompt_state_untouched():
+    """BatchDecoder.__init__ prefills its prompts through lm.forward with lm.cache / cache_len / max_seq swapped; forward() also records the
+    split-KV factor of "the prompt in the cache" - it belongs to the saved state, or an EAGER decode that continues the earlier prompt would merge its
+    split partials in another grouping than a DecodeGraph built for that prompt.  Prefill A (long enough for several splits), build a BatchDecoder over
+    other prompts, then decode A eagerly and by graph: same state, bit-identical logits."""
+    cfg = LM.Qwen2ConfigLite(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=512, vocab=512)          # head dim 128: the k_attn_decode split rule
+    sd = LM.random_qwen2_state_dict(cfg, seed=9, std=0.05)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = (torch.randn(3000, 256, device="cuda", generator=g) * 0.5).half()
+    lm = LM.Qwen2Model(sd, cfg, max_seq=4096)
+    first = int(lm.forward(A).argmax())
+    state = (lm.cache_len, lm._nsplit_prompt, lm.max_seq, [c.data_ptr() for c in lm.cache])
+    assert lm._nsplit_prompt == LM.decode_nsplit(128, 3000) and lm._nsplit_prompt > 2
+    LM.BatchDecoder(lm, [A[:300], A[:40]], max_new_tokens=4)                       # prompts with another split factor (2)
+    assert (lm.cache_len, lm._nsplit_prompt, lm.max_seq, [c.data_ptr() for c in lm.cache]) == state
+    dg = LM.DecodeGraph(lm, max_new_tokens=16)
+    assert dg.nsplit == lm._nsplit_prompt
+    eager = lm.forward(lm.embed_tokens(torch.tensor([first], device="cuda"))).clone()
+    lm.cache_len = 3000
+    dg.start(first)
+    dg.run(1)
+    assert torch.equal(dg.logits.view(torch.int32), eager.view(torch.int32))
+
+
 def test_rope_qk_row_equals_separate_ropes():
     """the fused decode RoPE (query row + K part of the cache row, one launch) is bit-identical to the two separate kernels"""
     g = torch.Generator(device="cuda").manual_seed(3)
