@@ -1410,6 +1410,123 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_l(const _Float16* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA may be in flight when the workgroup ends (hazard 3 of k_gemm_fat)
 }
 
+// k_gemm_skinny_l for the MANY-strip shapes of K = 3584 (gate/up, lm_head): the activations stay resident in registers for the lifetime of the
+// workgroup as in k_gemm_skinny_x (one fetch per WORKGROUP instead of one per strip), only the weights run through the per-wave LDS ring -
+// 8 stages of 4 KiB: 28 KiB of weight requests in flight per wave.  Same operands, same order: bit-identical to the other skinny kernels.
+template <int EPI, bool OUT_F32, int MG>
+__global__ __launch_bounds__(256) void k_gemm_skinny_lx(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
+                                                        const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
+                                                        void* __restrict__ Cout, int ldc, int M, int N, int strips_q, int strips_r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 3584, NST = 7, PD = 8, STB = 4096, CNT = (PD - 1) * 4;
+    constexpr int RING = 4 * PD * STB, RED = 3 * MG * 4 * 64 * 4, EB = 2048, NEB = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int s_lo = b * strips_q + min(b, strips_r), s_hi = s_lo + strips_q + (b < strips_r ? 1 : 0);
+    if (s_lo >= s_hi) return;
+    const int k_lo = wave * (K / 4);
+    const int total = (s_hi - s_lo) * NST;
+    char* ring = smem + wave * (PD * STB);
+    const unsigned ring_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(wave * (PD * STB));
+    float* red = reinterpret_cast<float*>(smem + RING);
+    char* ebuf = smem + RING + RED;
+    unsigned w_vo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = j * 4 + (lane >> 4); w_vo[j] = ((unsigned)r * (unsigned)K + (unsigned)(((lane & 15) ^ (r & 15)) * 8)) * 2u; }
+    const unsigned w_ext = (15u * (unsigned)K + 128u) * 2u;
+    unsigned f_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f_off[t] = (unsigned)(rl * 256 + (((t * 4 + g) ^ rl) << 4));
+    int is_strip = s_lo, is_st = 0, iq = 0;
+    auto issue = [&]() {
+        const bool live = iq < total;
+        char* dst = ring + (iq % PD) * STB;
+        if (wave == 0 && is_st == 0) {
+            char* e = ebuf + ((is_strip - s_lo) % NEB) * EB;
+            const int n0 = is_strip * 16;
+            lds_load16(R ? R + n0 : W, (live && R) ? ((unsigned)(M - 1) * (unsigned)ldr + 16u) * 2u : 0u, e, ((unsigned)(lane >> 1) * (unsigned)ldr + (unsigned)(lane & 1) * 8u) * 2u, 0u);
+            lds_load16(bias ? bias + n0 : W, (live && bias) ? 32u : 0u, e + 1024, (unsigned)lane * 16u, 0u);
+        }
+        const _Float16* wb = W + (size_t)is_strip * (size_t)(16 * K) + k_lo + is_st * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_load16(wb, live ? w_ext : 0u, dst + j * 1024, w_vo[j], 0u);
+        ++iq;
+        if (++is_st == NST) { is_st = 0; if (live) ++is_strip; }
+    };
+#pragma unroll
+    for (int u = 0; u < PD; ++u) issue();                      // the weight stream starts before the activations are fetched
+    sc_h8 xf[NST * 4][MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        int m = mg * 16 + rl;
+        m = m < M ? m : M - 1;
+        const _Float16* xp = A + (size_t)m * (size_t)lda + k_lo + g * 8;
+#pragma unroll
+        for (int u = 0; u < NST * 4; ++u) xf[u][mg] = *reinterpret_cast<const sc_h8*>(xp + u * 32);
+    }
+    int q = 0;
+    for (int strip = s_lo; strip < s_hi; ++strip) {
+        sc_f4 acc[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) acc[mg] = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NST; ++st, ++q) {
+            const unsigned sa = ring_lds + (unsigned)((q % PD) * STB);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+            sc_u4 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(sa + f_off[t]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) :: "memory");
+            issue();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg)
+                    acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sc_h8, wf[t]), xf[st * 4 + t][mg], acc[mg], 0, 0, 0);
+        }
+        asm volatile("s_barrier" ::: "memory");                // wave 0 has read the previous strip's partials
+        if (wave > 0) {
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave - 1) * MG + mg) * 4 + r) * 64 + lane] = acc[mg][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave == 0) {
+            const int n = strip * 16 + g * 4;
+            const char* e = ebuf + ((strip - s_lo) % NEB) * EB;
+            const sc_h4 bv = *reinterpret_cast<const sc_h4*>(e + 1024 + g * 8);
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[mg][r];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) t += red[((w * MG + mg) * 4 + r) * 64 + lane];
+                    v[r] = t + (bias ? (float)bv[r] : 0.f);
+                }
+                const int m = mg * 16 + rl;
+                if (m >= M) continue;
+                if (EPI == SC_EPI_SWIGLU) {
+                    const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[2], o1 = v[1] / (1.0f + __expf(-v[1])) * v[3];
+                    const sc_h2 o = {(_Float16)o0, (_Float16)o1};
+                    *reinterpret_cast<sc_h2*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + (n >> 1)) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epi_apply(v[r], EPI);
+                    if (R) { const sc_h4 r4 = *reinterpret_cast<const sc_h4*>(e + m * 32 + g * 8); for (int r = 0; r < 4; ++r) v[r] += (float)r4[r]; }
+                    if (OUT_F32) *reinterpret_cast<sc_f4*>(reinterpret_cast<float*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_f4{v[0], v[1], v[2], v[3]};
+                    else *reinterpret_cast<sc_h4*>(reinterpret_cast<_Float16*>(Cout) + (size_t)m * (size_t)ldc + n) = sc_h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int lda, const void* W, const void* bias, const void* R, int ldr, void* C, int ldc, int M, int N,
                 int K, int out_f32, int a_grp, int a_grp_stride, int a_grp_off, hipStream_t s) {
@@ -1459,6 +1576,20 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // lm_head); with one strip per workgroup (the 3584-row projections) loading x first only delays the weights: k_gemm_skinny_u
             if (K == 3584 && xres && N / 16 >= 2 * n_cu_x[dev]) {
                 const int strips = N / 16, gx = sc_launch_cu_count(n_cu_x[dev], s);
+                static int lx = -1;                   // SC_SKINNY_LX=0: weights as register operands (k_gemm_skinny_x) instead of the LDS ring (k_gemm_skinny_lx)
+                if (lx < 0) { const char* e = getenv("SC_SKINNY_LX"); lx = (e && e[0] == '0') ? 0 : 1; }
+                if (lx && lda % 8 == 0 && (!R || ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
+                    static bool lx_attr[16][4] = {};
+#define SC_LLX(F32, MGV, SLOT) do { constexpr int LDSB = 4 * 8 * 4096 + 3 * MGV * 4 * 64 * 4 + 4 * 2048;                                                        \
+                        if (!lx_attr[dev][SLOT]) { (void)hipFuncSetAttribute((const void*)k_gemm_skinny_lx<EPI, F32, MGV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); lx_attr[dev][SLOT] = true; } \
+                        hipLaunchKernelGGL((k_gemm_skinny_lx<EPI, F32, MGV>), dim3((unsigned)gx), block, LDSB, s, (const _Float16*)A, lda, (const _Float16*)W,           \
+                                           (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, strips / gx, strips % gx); } while (0)
+                    if (M <= 16) { if (out_f32) SC_LLX(true, 1, 0); else SC_LLX(false, 1, 1); }
+                    else { if (out_f32) SC_LLX(true, 2, 2); else SC_LLX(false, 2, 3); }
+#undef SC_LLX
+                    SC_CHECK_LAUNCH("sc_gemm_f16");
+                    return SC_OK;
+                }
 #define SC_LSX(F32, MGV) hipLaunchKernelGGL((k_gemm_skinny_x<EPI, F32, MGV>), dim3((unsigned)gx), block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
                                             (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, strips / gx, strips % gx)
                 if (M <= 16) { if (out_f32) SC_LSX(true, 1); else SC_LSX(false, 1); }
