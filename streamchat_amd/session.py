@@ -134,7 +134,8 @@ class StreamingSession:
         pieces = [short_emb] + [t.reshape(-1, t.shape[-1]) for t in path]
         _, _, _, _, embeds, _ = self.model.prepare_inputs_embeddings_for_multimodal(ids, None, None, None, None, [pieces], ["video"])
         slot = i % 2
-        self.slot_free[slot].wait()                                                     # the answer that used this cache two segments ago is out
+        if not self.slot_free[slot].wait(timeout=600):                                  # the answer that used this cache two segments ago is out
+            raise RuntimeError("session: the decode that owns this KV cache did not finish within 600 s")
         self.slot_free[slot].clear()
         lmv = self.views[slot]
         lmv.cache_len = 0
@@ -148,12 +149,14 @@ class StreamingSession:
         return slot, first, ev, embeds                                                  # (embeds kept alive until the decode has been enqueued)
 
     def _decode(self, i, slot, first, ev, keep):
-        torch.cuda.current_stream(self.device).wait_event(ev)
-        g = self.graphs[slot]
-        g.start(first)
-        self.records[i]["tokens"] = [first] + g.run(self.max_new - 1)
-        self.slot_free[slot].set()
-        del keep
+        try:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            g = self.graphs[slot]
+            g.start(first)
+            self.records[i]["tokens"] = [first] + g.run(self.max_new - 1)
+        finally:
+            self.slot_free[slot].set()                                                  # (also on an error: the reader / updater must not wait for ever)
+            del keep
 
     # ---- scheduling ----
     def submit(self, frames_u8, question, new_video=False):
@@ -198,7 +201,7 @@ class StreamingSession:
     def results(self):
         """waits for everything submitted so far"""
         if self.overlap:
-            self.w_mfma.drain()
+            self.w_mfma.drain()                                                         # (every decode job has been handed over once this returns)
             self.w_hbm.drain()
         torch.cuda.synchronize(self.device)
         return self.records
