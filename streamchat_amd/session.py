@@ -111,7 +111,7 @@ class StreamingSession:
     def _ingest_and_prefill(self, i, frames, question, new_video=False):
         rec = self.records[i]
         if new_video:                                                                   # the reference starts every video with an empty memory (:845-860)
-            self.tree, self.search_cache = None, U.CaptionEmbeddingCache()
+            self.tree, self.search_cache, self.banks = None, U.CaptionEmbeddingCache(), self.banks[-2:]     # (the last banks may still feed an answer in flight)
         feats = self.encoder.encode_frames_u8(frames)                                   # reader: [n, 576, D] fp16, a bank of its own per segment
         self.banks.append(feats)
         bank = [feats[j:j + 1] for j in range(feats.shape[0])]
