@@ -69,6 +69,9 @@ def parse_args(argv=None):
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
     p.add_argument("--max_new_tokens", type=int, default=256)
     p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
+    p.add_argument("--overlap", type=int, nargs="?", const=128, default=0, metavar="DECODE_CUS",
+                   help="reader / updater of the NEXT segment on a second host thread and CU partition while the answer is decoded on DECODE_CUS CUs "
+                        "(multiples of 32; the reference's three-thread design, previous_version/streaming_demo_llava_next_3.py:967-991; SURVEY 8(f).3)")
     p.add_argument("--memory_tree_dir", type=str, default=None,
                    help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
     return p.parse_args(argv)
@@ -131,7 +134,7 @@ def build_models(args):
 
 def inference_thread_with_memory_and_dialogue_retrival_test(long_memory_tree_cache, short_memory_buffer_cache, fps, model, embedding_model, tokenizer,
                                                             embedding_tokenizer, time_line, num_frames, conv_mode, chat, memory_config, args,
-                                                            save_file, question, labels, qa_class, time, output_loss=False):
+                                                            save_file, question, labels, qa_class, time, output_loss=False, **generate_kwargs):
     """reference :588-677: dialogue-memory prompt -> multi-modal answer -> append to the results JSON."""
     with open(save_file, "r", encoding="utf-8") as f:
         existing_data = json.load(f)
@@ -142,11 +145,59 @@ def inference_thread_with_memory_and_dialogue_retrival_test(long_memory_tree_cac
         output, process_time, generate_time = S.longva_inference_with_embedding_multi_modal(
             question, num_frames, conv_mode, model, embedding_model, tokenizer, embedding_tokenizer, chat, short_memory_buffer_cache,
             long_memory_tree_cache, searched_history, temperature=args.temperature, top_p=args.top_p, num_beams=args.num_beams,
-            max_new_tokens=args.max_new_tokens)
+            max_new_tokens=args.max_new_tokens, **generate_kwargs)
     existing_data.append({"time": time, "question": question, "label": labels, "predict": output, "class": qa_class, "process_time": process_time})
     with open(save_file, "w", encoding="utf-8") as f:
         json.dump(existing_data, f, ensure_ascii=False, indent=4)
     return output
+
+
+class Lookahead:
+    """--overlap: the reader + updater of the NEXT segment on a second host thread and the MFMA partition of the chip, started when the
+    current answer's prefill is done, while the answer's token loop runs on the decode partition (streamchat_amd/session.py explains the
+    partitioning).  The updater captions with its own view of the model (same weights, own KV cache and buffers: the reference keeps a
+    second replica for that, :697-700); a segment's reader / updater do not depend on the previous answer, only its prompt does."""
+
+    def __init__(self, model, decode_cus, device):
+        import threading
+        from streamchat_amd import ops
+        ncu = ops.device_info()["cu_count"]
+        dc = max(32, min(ncu - 32, int(decode_cus) // 32 * 32))
+        self.s_hbm, self.s_mfma = ops.masked_stream(0, dc, device), ops.masked_stream(dc, ncu - dc, device)
+        self.captioner = LM.LlavaQwenForCausalLM(model.lm.shared_view(), model.frame_encoder, model.eos_token_id)
+        self.captioner.generation_config, self.captioner.config = model.generation_config, model.config
+        self.device, self.threading = device, threading
+        self.thread, self.go, self.box = None, None, None
+
+    def arm(self, fn):
+        """`fn()` -> (feature_bank, tree, short) of the next segment; runs once `fire()` has been called"""
+        self.go, self.box = self.threading.Event(), {}
+
+        def work():
+            self.go.wait()
+            try:
+                with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma):
+                    self.box["out"] = fn()
+                    torch.cuda.current_stream().synchronize()
+            except BaseException as e:          # noqa: BLE001 - re-raised by take()
+                self.box["exc"] = e
+        self.thread = self.threading.Thread(target=work, name="streamchat-reader-updater", daemon=True)
+        self.thread.start()
+
+    def fire(self):
+        if self.go is not None:
+            self.go.set()
+
+    def take(self):
+        """the armed segment's result (None if nothing was armed)"""
+        if self.thread is None:
+            return None
+        self.go.set()                            # (an answer that ended at its first token never fired)
+        self.thread.join()
+        self.thread = None
+        if "exc" in self.box:
+            raise self.box["exc"]
+        return self.box["out"]
 
 
 def run_inference(args):
@@ -161,6 +212,7 @@ def run_inference(args):
     else:
         all_annotations = json.load(open(args.annotations, "r"))
     inference_count = 0
+    look = Lookahead(model, args.overlap, main_device) if args.overlap else None
     for anno in all_annotations:
         os.makedirs(args.memory_basic_dir, exist_ok=True)
         args.memory_file = "memory_{}.json".format(inference_count)
@@ -192,18 +244,33 @@ def run_inference(args):
         total_frames, frame_rate = cap.n, cap.fps
         frame_line = [0] + time_line
         long_memory_tree, short_memory_buffer = None, None
-        for questions, star, end in zip(question_list, frame_line[:-1], frame_line[1:]):
-            question, labels, qa_class = questions["question"], questions["answer"], questions["class"]
+        segments = list(zip(question_list, frame_line[:-1], frame_line[1:]))
+
+        def read_and_update(star, end, tree, short, summarizer):
             feature_bank = S.video_reader_thread_with_embedding(cap, total_frames, frame_rate, None, model, star, end, main_device, args.sample_rate,
                                                                 chunk_size=args.chunk_size)
             if len(feature_bank) > 0:
-                long_memory_tree, short_memory_buffer = S.updating_memory_buffer(
-                    feature_bank, long_memory_tree, model, tokenizer, args.multi_modal_memory, short_window=args.short_window,
+                tree, short = S.updating_memory_buffer(
+                    feature_bank, tree, summarizer, tokenizer, args.multi_modal_memory, short_window=args.short_window,
                     remember_window=args.remember_window, tau=args.tau, compress_rate=args.compress_rate, chunk_size=args.chunk_size,
                     num_clusters=args.num_clusters, interval=args.interval, batch_captions=args.batch_captions)
+            return feature_bank, tree, short
+        for si, (questions, star, end) in enumerate(segments):
+            question, labels, qa_class = questions["question"], questions["answer"], questions["class"]
+            ahead = look.take() if look is not None else None
+            if ahead is not None:
+                feature_bank, long_memory_tree, short_memory_buffer = ahead
+            else:
+                feature_bank, long_memory_tree, short_memory_buffer = read_and_update(star, end, long_memory_tree, short_memory_buffer, model)
+            gen_kw = {}
+            if look is not None:
+                if si + 1 < len(segments):           # the next segment's reader / updater start when this answer's prefill is done
+                    nxt = segments[si + 1]
+                    look.arm(lambda a=nxt[1], b=nxt[2], t=long_memory_tree, sh=short_memory_buffer: read_and_update(a, b, t, sh, look.captioner))
+                gen_kw = dict(on_prefill_done=look.fire, decode_stream=look.s_hbm)
             output = inference_thread_with_memory_and_dialogue_retrival_test(
                 long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
-                args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"])
+                args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"], **gen_kw)
             # persist the dialogue turn and refresh the retrieval index (reference :918-920)
             memory = save_local_memory(memory, [[question, output]], user_name, args)
             _, _, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)

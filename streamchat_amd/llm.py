@@ -421,7 +421,7 @@ class DecodeGraph:
         for t, v in zip((self.tok, self.pos, self.len, self.cnt, self.nprev), snap):
             t.copy_(v)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (another host thread may be driving its own stream: session.py)
             self.logits = self._body()
         self._captured_ptrs = self._ptrs()
         for t, v in zip((self.tok, self.pos, self.len, self.cnt, self.nprev), snap):
@@ -569,7 +569,7 @@ class BatchDecoder:
             restore = lambda: [t.copy_(v) for t, v in zip(state, snap)]
             restore()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._graph_body(sp)
             restore()
         steps = 1
@@ -695,7 +695,20 @@ class LlavaQwenForCausalLM:
                 dg = self._dgs[key] = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256), sampling=sp)
             self._dg = dg
             dg.start(first)
-            rest = dg.run(max_new_tokens - 1, eos=eos)
+            # round 5 (the entry point's --overlap): the prefill is done and its first token is on the host - `on_prefill_done`
+            # lets the caller start the next segment's reader / updater on another host thread, and the HBM-bound token loop moves to
+            # `decode_stream` (a CU partition of its own) so that the two run beside each other.  Same kernels, same tokens.
+            cb, ds = kwargs.get("on_prefill_done"), kwargs.get("decode_stream")
+            if cb is not None:
+                cb()
+            if ds is not None:
+                cur = torch.cuda.current_stream(self.device)
+                ds.wait_stream(cur)
+                with torch.cuda.stream(ds):
+                    rest = dg.run(max_new_tokens - 1, eos=eos)
+                cur.wait_stream(ds)
+            else:
+                rest = dg.run(max_new_tokens - 1, eos=eos)
             return torch.tensor([[first] + rest], dtype=torch.long, device=self.device)
         new = []
         for step in range(max_new_tokens):

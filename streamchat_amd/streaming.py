@@ -139,7 +139,7 @@ def build_answer_prompt(question, most_fine_grad_text, history_prompt, mm_use_im
 
 def longva_inference_with_embedding_multi_modal(question, num_frames, conv_mode, model, embedding_model, tokenizer, embedding_tokenizer, chat,
                                                 short_memory_buffer_cache, long_memory_tree_cache, history_prompt=None, temperature=0.2,
-                                                top_p=None, num_beams=1, max_new_tokens=256, search_cache=None):
+                                                top_p=None, num_beams=1, max_new_tokens=256, search_cache=None, **generate_kwargs):
     """Mirror of :164-264: retrieve long-term memory for the question, concatenate [short | long] frame tokens, build the prompt,
     tokenise with the -200 sentinel, generate.  Returns (text, process_time, generate_time) like upstream; `temperature` etc. are
     explicit (upstream reads the global `args`)."""
@@ -165,7 +165,7 @@ def longva_inference_with_embedding_multi_modal(question, num_frames, conv_mode,
     with torch.no_grad():        # (not inference_mode: the persistent activation buffers are reused outside)
         output_ids = model.generate_with_image_embedding(input_ids, image_embeddings=[image_embeddings], modalities=["video"],
                                                          do_sample=True if temperature > 0 else False, temperature=temperature, top_p=top_p,
-                                                         num_beams=num_beams, max_new_tokens=max_new_tokens, use_cache=False)
+                                                         num_beams=num_beams, max_new_tokens=max_new_tokens, use_cache=False, **generate_kwargs)
     outputs = tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
     time_2 = time.time()
     return outputs, time_1 - time_0, time_2 - time_1

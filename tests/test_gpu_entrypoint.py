@@ -35,3 +35,32 @@ def test_parse_args_has_reference_flags():
     for k, v in dict(chunk_size=20, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5, compress_rate=1, sample_rate=0.5,
                      temperature=0.2, num_beams=1, memory_search_top_k=1, conv_mode="video-chatgpt_v1", mode="off_line").items():
         assert getattr(a, k) == v
+
+
+def test_overlap_flag_gives_the_same_answers_and_memory(tmp_path, monkeypatch):
+    """--overlap: the next segment's reader / updater on a second host thread + CU partition while the answer is decoded on its own
+    partition.  With every generate forced greedy (the reference samples: Q12) the answers, the dialogue memory and the persisted memory tree equal
+    those of the serial run."""
+    import torch
+    import inference_streaming_longva_v2 as E
+    from streamchat_amd import llm as LM
+    from streamchat_amd.persistence import load_memory_tree
+    real = LM.resolve_sampling
+    monkeypatch.setattr(LM, "resolve_sampling", lambda *a, **k: LM.Sampling(0.0, 0, 1.0, real(*a, **k).repetition_penalty))
+    runs = {}
+    for name, extra in (("serial", []), ("overlap", ["--overlap", "128"])):
+        d = tmp_path / name
+        args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(d / "mem"), "--save_file", str(d / "out.json"),
+                             "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "2", "--tiny", "--chunk_size", "4",
+                             "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3", "--max_new_tokens", "12",
+                             "--multi_modal_memory", "--memory_tree_dir", str(d / "trees"), "--batch_captions"] + extra)
+        os.makedirs(d, exist_ok=True)
+        import numpy as np, random
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        E.run_inference(args)
+        out = json.load(open(d / "out.json"))
+        nodes, short, _ = load_memory_tree(str(d / "trees" / "video_1"))
+        runs[name] = dict(answers=[(r["question"], r["predict"]) for r in out], texts=[n.text for n in nodes], rows=[int(n.centroids.shape[0]) for n in nodes],
+                          short=[float(t.float().sum()) for t in short])
+    assert len(runs["serial"]["answers"]) == 4
+    assert runs["overlap"] == runs["serial"]
