@@ -67,6 +67,7 @@ def parse_args(argv=None):
     p.add_argument("--sentence_model_id", type=str, default=None, help="all-MiniLM-L6-v2 directory (dialogue-memory embedder, local_doc_qa.py:193)")
     p.add_argument("--vision_tower", type=str, default=None, help="CLIP ViT-L/14-336 directory if the LongVA checkpoint carries no tower weights")
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
+    p.add_argument("--synthetic_breakpoints", type=int, default=2, help="questions per synthetic video (one every 60 s)")
     p.add_argument("--max_new_tokens", type=int, default=256)
     p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
     p.add_argument("--overlap", type=int, nargs="?", const=128, default=0, metavar="DECODE_CUS",
@@ -208,7 +209,7 @@ def run_inference(args):
     if args.synthetic:
         all_annotations = [{"info": {"video_path": f"synthetic_{i}", "class_1": "synthetic"},
                             "breakpoint": [{"time": 60 * (j + 1), "question": f"what happened around {synthetic.caption(j, words=3)}?", "answer": "n/a",
-                                            "class": "synthetic"} for j in range(2)]} for i in range(args.synthetic)]
+                                            "class": "synthetic"} for j in range(args.synthetic_breakpoints)]} for i in range(args.synthetic)]
     else:
         all_annotations = json.load(open(args.annotations, "r"))
     inference_count = 0
