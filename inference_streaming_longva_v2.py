@@ -167,8 +167,9 @@ class Lookahead:
         self.s_hbm, self.s_mfma = ops.masked_stream(0, dc, device), ops.masked_stream(dc, ncu - dc, device)
         self.captioner = LM.LlavaQwenForCausalLM(model.lm.shared_view(), model.frame_encoder, model.eos_token_id)
         self.captioner.generation_config, self.captioner.config = model.generation_config, model.config
+        self.s_full = torch.cuda.Stream(device)                  # the reader / updater take the whole chip once the answer beside them is out
         self.device, self.threading = device, threading
-        self.thread, self.go, self.box = None, None, None
+        self.thread, self.go, self.box, self.decoding = None, None, None, False
 
     def arm(self, fn):
         """`fn()` -> (feature_bank, tree, short) of the next segment; runs once `fire()` has been called"""
@@ -176,9 +177,14 @@ class Lookahead:
 
         def work():
             self.go.wait()
+            from streamchat_amd import ops
             try:
                 with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma):
-                    self.box["out"] = fn()
+                    ops.move_to_stream_when(lambda: not self.decoding, self.s_full)
+                    try:
+                        self.box["out"] = fn()
+                    finally:
+                        ops.move_to_stream_when(None, None)
                     torch.cuda.current_stream().synchronize()
             except BaseException as e:          # noqa: BLE001 - re-raised by take()
                 self.box["exc"] = e
@@ -187,7 +193,11 @@ class Lookahead:
 
     def fire(self):
         if self.go is not None:
+            self.decoding = True
             self.go.set()
+
+    def answer_done(self):
+        self.decoding = False
 
     def take(self):
         """the armed segment's result (None if nothing was armed)"""
@@ -272,6 +282,8 @@ def run_inference(args):
             output = inference_thread_with_memory_and_dialogue_retrival_test(
                 long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
                 args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"], **gen_kw)
+            if look is not None:
+                look.answer_done()
             # persist the dialogue turn and refresh the retrieval index (reference :918-920)
             memory = save_local_memory(memory, [[question, output]], user_name, args)
             _, _, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)

@@ -117,8 +117,30 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+import threading as _threading
+
+_tls = _threading.local()
+
+
+def move_to_stream_when(condition, stream):
+    """THIS host thread's launches move to `stream` (ordered behind everything it has enqueued so far) at its first kernel launch after
+    `condition()` turns true - session.py / the entry point's --overlap: a reader / updater job that started on its CU partition takes the
+    whole chip as soon as the answer decode beside it has finished.  `condition` None cancels.  Checked in stream_ptr(), i.e. at every
+    launch of the library; never while the thread's stream is being captured."""
+    _tls.pending = None if condition is None else (condition, stream)
+
+
 def stream_ptr(device=None):
     import torch
+    p = getattr(_tls, "pending", None)
+    if p is not None and p[0]() and not torch.cuda.is_current_stream_capturing():
+        _tls.pending = None
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != p[1].cuda_stream:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            p[1].wait_event(ev)
+            torch.cuda.set_stream(p[1])
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -9,7 +9,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr, StreamChatHipError
+from ._lib import check, ptr, stream_ptr, move_to_stream_when, StreamChatHipError   # noqa: F401
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # openai/clip-vit-large-patch14-336 preprocessor_config
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)

@@ -180,7 +180,12 @@ class StreamingSession:
             self.records[i]["mfma_partitioned"] = shared
             try:
                 with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_mfma if shared else self.s_mfma_full):
-                    slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
+                    if shared:                                     # ... and take the whole chip as soon as that answer is out
+                        ops.move_to_stream_when(lambda: self._pending["hbm"] == 0, self.s_mfma_full)
+                    try:
+                        slot, first, ev, keep = self._ingest_and_prefill(i, frames_u8, question, new_video)
+                    finally:
+                        ops.move_to_stream_when(None, None)
             finally:
                 count("mfma", -1)
 

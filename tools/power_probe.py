@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sustained launches of one hot kernel while sampling the package power and the shader clock (rocm-smi): shows which kernels sit on
-the board's power cap.  usage: python tools/power_probe.py attn49k|gemm_llm|gemm_llm_8wave|gemm_vit|vit_attn|decode|idle [seconds]"""
+the board's power cap.  usage: python tools/power_probe.py attn49k|gemm_llm|gemm_llm_8wave|gemm_llm_zeros|gemm_llm_const|gemm_vit|gemm_vit_zeros|vit_attn|decode|idle [seconds]"""
 import os, subprocess, sys, threading, time
 what = sys.argv[1] if len(sys.argv) > 1 else "attn49k"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
@@ -39,9 +39,17 @@ elif what == "decode":
     lm.reset_cache(); lm.cache_len = 49152
     dg = LM.DecodeGraph(lm, max_new_tokens=4096); dg.start(1); dg.capture()
     fn = lambda: dg.graph.replay(); flops = 16.92e9          # bytes per token: the printed "TFLOP/s" column is GB/s / 1000 for this row
-elif what in ("gemm_llm", "gemm_vit", "gemm_llm_8wave"):
-    M, N, K = (295424, 4096, 1024) if what == "gemm_vit" else (48994, 3584, 18944)
-    a, w = r(M, K), r(N, K) * (K ** -0.5); out = torch.empty(M, N, device="cuda", dtype=torch.float16)
+elif what in ("gemm_llm", "gemm_vit", "gemm_llm_8wave", "gemm_llm_zeros", "gemm_llm_const", "gemm_vit_zeros"):
+    # *_zeros / *_const (round 5): the SAME launches on operands that do not toggle the datapath - what the schedule delivers when the board's
+    # power cap is not the limit (uniform random fp16 is the worst case for switching power)
+    M, N, K = (295424, 4096, 1024) if what.startswith("gemm_vit") else (48994, 3584, 18944)
+    if what.endswith("_zeros"):
+        a, w = torch.zeros(M, K, device="cuda", dtype=torch.float16), torch.zeros(N, K, device="cuda", dtype=torch.float16)
+    elif what.endswith("_const"):
+        a, w = torch.full((M, K), 0.5, device="cuda", dtype=torch.float16), torch.full((N, K), 0.25, device="cuda", dtype=torch.float16)
+    else:
+        a, w = r(M, K), r(N, K) * (K ** -0.5)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float16)
     fn = lambda: ops.gemm(a, w, out=out); flops = 2.0 * M * N * K
 else:
     fn = None; flops = 0.0
