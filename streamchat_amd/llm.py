@@ -441,7 +441,9 @@ class DecodeGraph:
         done, toks = 0, []
         while done < n_tokens:
             step = n_tokens - done if not eos else min(check_every, n_tokens - done)
-            for _ in range(step):
+            for r in range(step):
+                if r % 32 == 0:
+                    ops.stream_ptr(self.lm.device)          # (a pending ops.move_to_stream_when of this thread takes effect between replays)
                 self.graph.replay()
             done += step
             if eos:

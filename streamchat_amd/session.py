@@ -194,7 +194,12 @@ class StreamingSession:
                 self.records[i]["decode_partitioned"] = shared
                 try:
                     with torch.no_grad(), torch.cuda.device(self.device), torch.cuda.stream(self.s_hbm if shared else self.s_hbm_full):
-                        self._decode(i, slot, first, ev, keep)
+                        if shared:
+                            ops.move_to_stream_when(lambda: self._pending["mfma"] == 0, self.s_hbm_full)
+                        try:
+                            self._decode(i, slot, first, ev, keep)
+                        finally:
+                            ops.move_to_stream_when(None, None)
                 finally:
                     count("hbm", -1)
             count("hbm", +1)
