@@ -468,18 +468,26 @@ def build_info() -> str:
     return _lib.load().sc_build_info().decode()
 
 
+_masked_streams = {}
+
+
 def masked_stream(cu_first: int, cu_count: int, device=None):
     """A torch stream restricted to the CUs [cu_first, cu_first + cu_count) (sc_stream_create_masked: hipExtStreamCreateWithCUMask; consecutive
-    CU-mask bits go round-robin over the XCDs, use multiples of 8).  Round 5: the HBM-bound answer decode on a few CUs beside the MFMA-bound
-    encode / prefill of the next segment on the rest.  The stream lives as long as the returned object."""
+    CU-mask bits go round-robin over the 8 XCDs x 4 shader engines: use multiples of 32).  Round 5: the HBM-bound answer decode on one partition
+    beside the MFMA-bound encode / prefill of the next segment on the other.  ONE stream per (device, range) and process: a second request returns
+    the same object (the library keeps the partition size of at most 32 masked streams; they are never destroyed - torch may hold events
+    recorded on them until interpreter exit)."""
     from ctypes import byref, c_void_p
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(cu_first), int(cu_count))
+    if key in _masked_streams:
+        return _masked_streams[key]
     h = c_void_p()
     with torch.cuda.device(dev):
         check(_lib.load().sc_stream_create_masked(int(cu_first), int(cu_count), 0, byref(h)), "sc_stream_create_masked")
     s = torch.cuda.ExternalStream(h.value, device=dev)
-    s._sc_handle = h                    # (not destroyed on purpose: torch may still hold events recorded on it at interpreter exit)
-    s.cu_count = int(cu_count)
+    s._sc_handle = h
+    _masked_streams[key] = s
     return s
 
 
