@@ -70,3 +70,20 @@ def test_no_cpu_fallback():
     from streamchat_amd._lib import StreamChatHipError
     with pytest.raises(StreamChatHipError):
         ops.kmeans_fit(torch.zeros(8, 16), 2, [0, 1])        # CPU tensor: refused, never computed on the host
+
+
+def test_rope_qkv_rows_rejects_bad_arguments_before_any_device_work(hip_lib):
+    """ABI 6 entry point: argument errors come back as SC_ERR_* with a message, without touching the device (runs without a GPU)."""
+    import ctypes
+    f = hip_lib.sc_rope_qkv_rows_f16
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                  ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    hip_lib.sc_last_error.restype = ctypes.c_char_p
+    assert f(None, 4608, None, None, 64, None, 2, 28, 4, 128, None, 3584, None, 0, 1024, 16, None) < 0
+    assert b"null pointer" in hip_lib.sc_last_error()
+    p = ctypes.c_void_p(4096)                                 # any aligned non-null value: the checks below fire before it is dereferenced
+    assert f(p, 100, p, p, 64, p, 2, 28, 4, 128, p, 3584, p, 0, 1024, 16, None) < 0          # ldx smaller than (28 + 8) * 128
+    assert b"leading dimensions" in hip_lib.sc_last_error()
+    assert f(p, 4608, p, p, 64, p, 2, 28, 4, 100, p, 3584, p, 0, 1024, 16, None) < 0         # Dh % 8 != 0
+    assert b"bad sizes" in hip_lib.sc_last_error()
