@@ -66,3 +66,29 @@ def test_worker_reraises_on_the_callers_thread():
     w.submit(lambda: None)
     w.drain()
     w.close()
+
+
+def test_move_to_stream_when_switches_at_the_next_launch_and_keeps_the_order():
+    """ops.move_to_stream_when: THIS thread's launches move to another stream at the first library launch after the condition turns true, ordered
+    behind what was enqueued before; cancelled by (None, None); never fires while the condition is false."""
+    dev = torch.device("cuda:0")
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    flag = {"go": False}
+    x = torch.randn(64, 1024, device=dev).half()
+    g = torch.ones(1024, device=dev).half()
+    with torch.cuda.stream(s1):
+        ops.move_to_stream_when(lambda: flag["go"], s2)
+        a = ops.rmsnorm(x, g, 1e-6)
+        assert torch.cuda.current_stream(dev) == s1                     # condition false: nothing moves
+        big = torch.randn(4096, 4096, device=dev)
+        for _ in range(20):
+            big = big @ big * 1e-3                                       # keep s1 busy so that an unordered switch would be seen
+        y = big[:64, :1024].half().contiguous()
+        flag["go"] = True
+        b = ops.rmsnorm(y, g, 1e-6)                                      # switches to s2 first, behind everything enqueued on s1
+        assert torch.cuda.current_stream(dev) == s2
+        ops.move_to_stream_when(None, None)
+    assert torch.cuda.current_stream(dev) != s2                          # the `with` restored the caller's stream
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.rms_norm(y.float(), (1024,), g.float(), 1e-6)          # from the FINAL y: b must have waited for it
+    assert (b.float() - ref).abs().max().item() < 2e-2 and torch.isfinite(a.float()).all()
