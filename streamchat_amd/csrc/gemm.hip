@@ -28,6 +28,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 
+// internal: SC_EPI_ROPE where EVERY column is a rotary head (the q projection: lead_cols == N).  Round 5: with the plain-column branch compiled in next
+// to the rotary one, hipcc spills 101 VGPRs (280 B of scratch per lane) in the rotary instantiation; without it 9 / 0.
+constexpr int SC_EPI_ROPE_ALL = 6;
+
 __device__ __forceinline__ float epi_apply(float x, int epi) {
     if (epi == SC_EPI_QUICK_GELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     if (epi == SC_EPI_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
 #pragma unroll
             for (int nj = 0; nj < 8; ++nj) rr[nj] = *reinterpret_cast<const sc_u2*>(rslab + (acc_o ^ (nj * 32)));
         };
-        if (EPI == SC_EPI_ROPE && n0 < lead_cols) {
+        if (EPI == SC_EPI_ROPE_ALL || (EPI == SC_EPI_ROPE && n0 < lead_cols)) {
             // Rotary epilogue (Qwen2 q / k projections): the wave's 128 columns are ONE head; rotate-half pairs column j with j + 64, i.e.
             // the 16-column tile nj with nj + 4 of the SAME lane.  x' = (x_j cos - x_{j+64} sin, x_{j+64} cos + x_j sin) on the fp32
             // accumulators + bias with the fp32 table row of the token's position (row m -> position pos0 + m; [cos(64) | sin(64)], the
@@ -1740,6 +1744,7 @@ extern "C" int sc_gemm_headed_f16(const void* A, int lda, const void* W, const v
           ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0))
         return sc_fail(SC_ERR_UNSUPPORTED, "sc_gemm_headed_f16: needs N %% 256 == 0, K %% 128 == 0, lda %% 8 == 0, ldc %% 8 == 0 and 16-byte aligned A / W / C / bias");
     hipStream_t s = (hipStream_t)stream;
+    if (mode == SC_EPI_ROPE && lead_cols >= N) return launch_headed<SC_EPI_ROPE_ALL>(A, lda, W, bias, C, ldc, M, N, K, rope_tab, pos0, N, 1.0f, s);
     if (mode == SC_EPI_ROPE) return launch_headed<SC_EPI_ROPE>(A, lda, W, bias, C, ldc, M, N, K, rope_tab, pos0, lead_cols, 1.0f, s);
     return launch_headed<SC_EPI_COLSCALE>(A, lda, W, bias, C, ldc, M, N, K, nullptr, 0, lead_cols, col_scale, s);
 }
