@@ -26,7 +26,12 @@ def sampler():
 r = lambda *s: torch.randn(*s, device="cuda").half()
 if what.startswith("attn49k"):
     S, Hq, Hkv, Dh = 49152, 28, 4, 128
-    q, k, v = r(1, S, Hq * Dh), r(1, S, Hkv * Dh), r(1, S, Hkv * Dh); out = torch.empty_like(q)
+    if what.endswith("_zeros"):
+        z = lambda *s: torch.zeros(*s, device="cuda", dtype=torch.float16)
+        q, k, v = z(1, S, Hq * Dh), z(1, S, Hkv * Dh), z(1, S, Hkv * Dh)
+    else:
+        q, k, v = r(1, S, Hq * Dh), r(1, S, Hkv * Dh), r(1, S, Hkv * Dh)
+    out = torch.empty_like(q)
     fn = lambda: ops.attention(q, k, v, Hq, Hkv, Dh, Dh ** -0.5, True, out=out); flops = 4.0 * Hq * S * S * Dh * 0.5
 elif what == "vit_attn":
     B, S, H, Dh = 512, 577, 16, 64
