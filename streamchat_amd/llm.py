@@ -292,6 +292,13 @@ def _lib_pick_bytes(B):
 
 _UNSET = object()
 
+# The default CUDA generator of a device has ONE capture state: while a host thread captures a graph (torch.cuda.graph puts the generator into
+# capture mode, whether or not the graph draws from it), a draw or the replay of a sampling graph on ANOTHER host thread fails ("... during
+# capture").  Since round 5 two host threads generate at the same time (session.py, the entry point's --overlap: the answer on one, the chunk
+# captions on the other): captures, eager draws and sampling replays take this lock.  Uncontended it costs ~0.1 us per replay.
+import threading as _threading
+_GEN_LOCK = _threading.RLock()
+
 
 class Sampling(typing.NamedTuple):
     """What turns logits into the next token: HF's processor chain as `generate` builds it (transformers generation/utils.py
@@ -405,11 +412,12 @@ class DecodeGraph:
     def capture(self):
         # the warm-up step and the capture itself draw from the default CUDA generator when sampling: put its state back afterwards, so
         # that the tokens of a seeded run do not depend on whether the graph already existed
-        rng_state = torch.cuda.get_rng_state(self.lm.device)
-        try:
-            self._capture()
-        finally:
-            torch.cuda.set_rng_state(rng_state, self.lm.device)
+        with _GEN_LOCK:
+            rng_state = torch.cuda.get_rng_state(self.lm.device)
+            try:
+                self._capture()
+            finally:
+                torch.cuda.set_rng_state(rng_state, self.lm.device)
 
     def _capture(self):
         snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone(), self.nprev.clone())
@@ -444,7 +452,11 @@ class DecodeGraph:
             for r in range(step):
                 if r % 32 == 0:
                     ops.stream_ptr(self.lm.device)          # (a pending ops.move_to_stream_when of this thread takes effect between replays)
-                self.graph.replay()
+                if self.temperature > 0:
+                    with _GEN_LOCK:                         # the graph draws from the default generator
+                        self.graph.replay()
+                else:
+                    self.graph.replay()
             done += step
             if eos:
                 toks = self.out[:done].cpu().tolist()
@@ -522,7 +534,11 @@ class BatchDecoder:
     def _pick(self, logits, sp, generator=None):
         """next token per sequence on the device (sampling.hip): HF's processor chain of `sp` over the ids each sequence generated so far
         (self.hist[b, :nprev]); the uniform draws come from `generator` (the default CUDA generator inside a captured graph)"""
-        u = torch.rand(logits.shape[0], device=logits.device, generator=generator) if sp.temperature > 0 else None
+        if sp.temperature > 0:
+            with _GEN_LOCK:
+                u = torch.rand(logits.shape[0], device=logits.device, generator=generator)
+        else:
+            u = None
         if sp.plain:
             return ops.pick_token(logits, sp.temperature, u, ws=self._ws_pick)
         return ops.sample_token(logits, sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=self.hist, n_prev=self.nprev, ws=self._ws_pick)
@@ -571,13 +587,17 @@ class BatchDecoder:
             restore = lambda: [t.copy_(v) for t, v in zip(state, snap)]
             restore()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with _GEN_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (_GEN_LOCK: see its definition)
                 self._graph_body(sp)
             restore()
         steps = 1
         while steps < max_new_tokens:
             if graph is not None:
-                graph.replay()
+                if sp.temperature > 0:
+                    with _GEN_LOCK:
+                        graph.replay()
+                else:
+                    graph.replay()
             else:
                 nxt = self._pick(self.step(self.tok), sp, generator)
                 self.hist[:, steps] = nxt
@@ -664,7 +684,11 @@ class LlavaQwenForCausalLM:
 
     def _next(self, logits, sp, prev, generator=None):
         """one token from the last-row logits through the processor chain of `sp`; prev = ids generated so far (python list)"""
-        u = torch.rand(1, device=self.device, generator=generator) if sp.temperature > 0 else None
+        if sp.temperature > 0:
+            with _GEN_LOCK:
+                u = torch.rand(1, device=self.device, generator=generator)
+        else:
+            u = None
         if sp.plain:
             return int(ops.pick_token(logits, sp.temperature, u).item())
         pv = torch.tensor([prev if prev else [0]], dtype=torch.int64, device=self.device)
