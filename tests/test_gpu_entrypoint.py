@@ -66,14 +66,15 @@ def test_overlap_flag_gives_the_same_answers_and_memory(tmp_path, monkeypatch):
     assert runs["overlap"] == runs["serial"]
 
 
-def test_overlap_with_the_reference_sampling_settings_runs_to_completion(tmp_path):
+@pytest.mark.parametrize("batched", [False, True])
+def test_overlap_with_the_reference_sampling_settings_runs_to_completion(tmp_path, batched):
     """--overlap with the reference's own generation settings (temperature 0.2 answers, temperature 0.1 captions: both host threads draw from the
     default CUDA generator inside their decode graphs, so texts are not comparable - Q12); two videos, three questions each."""
     import inference_streaming_longva_v2 as E
     args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(tmp_path / "mem"), "--save_file", str(tmp_path / "out.json"),
                          "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "2", "--synthetic_breakpoints", "3", "--tiny",
                          "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3", "--max_new_tokens", "40",
-                         "--multi_modal_memory", "--overlap"])
+                         "--multi_modal_memory", "--overlap"] + (["--batch_captions"] if batched else []))
     assert args.overlap == 128
     E.run_inference(args)
     out = json.load(open(tmp_path / "out.json"))
