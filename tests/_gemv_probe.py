@@ -46,6 +46,13 @@ def main(path):
                 gate_up=(cases["gate_up"][0], xb, None, None, "swiglu", False), down=(cases["down"][0], xmb, None, resb, "none", False)).items():
             y = ops.gemm(a, w, b, residual=r, epilogue=epi, out_f32=f32)
             out[f"gemm{M}_{name}"] = y.cpu().numpy().view(np.uint32 if f32 else np.uint16)
+    # the LDS-ring skinny kernel on OTHER widths (run-time K: 2048 = the smallest it takes, 2560, 3072, 4096 = BERT-large's fc2) and row counts around the
+    # 16-row tile boundary, few strips and many, with bias / residual / fp32 output: against the run-time-loop kernel bit for bit
+    for (M, N, K, has_b, has_r, f32) in [(1, 1024, 4096, True, True, False), (5, 128, 2048, True, False, True), (16, 256, 2560, False, True, False),
+                                         (17, 384, 3072, True, True, False), (32, 1024, 2048, False, False, True), (26, 8192, 2048, True, False, False)]:
+        a, w = rn(M, K), rn(N, K, std=0.03)
+        y = ops.gemm(a, w, rn(N, std=0.1) if has_b else None, residual=rn(M, N) if has_r else None, out_f32=f32)
+        out[f"gemm_{M}x{N}x{K}"] = y.cpu().numpy().view(np.uint32 if f32 else np.uint16)
     torch.cuda.synchronize()
     np.savez(path, **out)
 
