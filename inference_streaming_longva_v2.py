@@ -169,11 +169,13 @@ class Lookahead:
         self.captioner.generation_config, self.captioner.config = model.generation_config, model.config
         self.s_full = torch.cuda.Stream(device)                  # the reader / updater take the whole chip once the answer beside them is out
         self.device, self.threading = device, threading
-        self.thread, self.go, self.box, self.decoding = None, None, None, False
+        self.thread, self.go, self.box, self.decoding, self.busy = None, None, None, False, False
 
     def arm(self, fn):
         """`fn()` -> (feature_bank, tree, short) of the next segment; runs once `fire()` has been called"""
         self.go, self.box = self.threading.Event(), {}
+
+        self.busy = True
 
         def work():
             self.go.wait()
@@ -188,6 +190,8 @@ class Lookahead:
                     torch.cuda.current_stream().synchronize()
             except BaseException as e:          # noqa: BLE001 - re-raised by take()
                 self.box["exc"] = e
+            finally:
+                self.busy = False                # (the answer's token loop moves back to the whole chip: see run_inference)
         self.thread = self.threading.Thread(target=work, name="streamchat-reader-updater", daemon=True)
         self.thread.start()
 
@@ -274,16 +278,23 @@ def run_inference(args):
             else:
                 feature_bank, long_memory_tree, short_memory_buffer = read_and_update(star, end, long_memory_tree, short_memory_buffer, model)
             gen_kw = {}
-            if look is not None:
-                if si + 1 < len(segments):           # the next segment's reader / updater start when this answer's prefill is done
-                    nxt = segments[si + 1]
-                    look.arm(lambda a=nxt[1], b=nxt[2], t=long_memory_tree, sh=short_memory_buffer: read_and_update(a, b, t, sh, look.captioner))
+            if look is not None and si + 1 < len(segments):
+                # the next segment's reader / updater start when this answer's prefill is done, and the answer's token loop runs on the decode
+                # partition for as long as they are busy (the last answer of a video has nothing beside it: whole chip)
+                nxt = segments[si + 1]
+                look.arm(lambda a=nxt[1], b=nxt[2], t=long_memory_tree, sh=short_memory_buffer: read_and_update(a, b, t, sh, look.captioner))
                 gen_kw = dict(on_prefill_done=look.fire, decode_stream=look.s_hbm)
-            output = inference_thread_with_memory_and_dialogue_retrival_test(
-                long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
-                args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"], **gen_kw)
-            if look is not None:
-                look.answer_done()
+                from streamchat_amd import ops
+                ops.move_to_stream_when(lambda: look.decoding and not look.busy, torch.cuda.current_stream(torch.device(main_device)))
+            try:
+                output = inference_thread_with_memory_and_dialogue_retrival_test(
+                    long_memory_tree, short_memory_buffer, frame_rate, model, embedding_model, tokenizer, embedding_tokenizer, time_line,
+                    args.num_frames, conv_mode, None, memory_config, args, save_file, question, labels, qa_class, questions["time"], **gen_kw)
+            finally:
+                if look is not None:
+                    from streamchat_amd import ops
+                    ops.move_to_stream_when(None, None)
+                    look.answer_done()
             # persist the dialogue turn and refresh the retrieval index (reference :918-920)
             memory = save_local_memory(memory, [[question, output]], user_name, args)
             _, _, memory, user_name, user_memory_index = enter_name(user_name, memory, local_memory_qa, args)
