@@ -661,6 +661,10 @@ def main():
         pass
     roof = mfma_roof("k_gemm_fat (+k_gemm256/k_gemm128/k_gemm_skinny for K%128, small-M and fp32-out shapes)", (n, ms, work))
     roof.update(traffic=traffic, traffic_source=TRAFFIC_PROFILE if traffic else None, flops_per_launch=round(work / max(n, 1)))
+    # (context for `frac`, measured once with tools/probes/probe_mfma_energy.hip: a register-resident loop of v_mfma_f32_16x16x32_f16 on random operands - no LDS,
+    #  no memory - issues one MFMA per 16.1 clocks and still delivers 0.78 of the nominal peak, because it alone puts the package on its 1400 W cap at 1.89 GHz)
+    roof.update(power_cap_note="register-resident MFMA loop, random fp16 operands: 0.78 of peak at the 1400 W cap (1.89 GHz); with k_gemm_fat's LDS fragment reads 0.70 - "
+                               "profiles/r05_run_aa_mfma_energy_probe.jsonl")
     # per-stage rooflines: the ViT and LLM halves of the two MFMA kernel families, the HBM-bound k-means (1x = SURVEY 8(d)'s algorithmic
     # bytes: one read of X per Lloyd iteration; 2x = what the two-pass kernel moves), decode below
     stages = dict(vit_gemm=mfma_roof("k_gemm* (ViT-L + projector)", fam("k_gemm", ("encode",))),
