@@ -537,6 +537,9 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 #ifndef FAT_STAMP
 #define FAT_STAMP(slot)
 #endif
+#ifndef SC_FAT_SNAKE
+#define SC_FAT_SNAKE 1
+#endif
 template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
@@ -655,8 +658,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
 #pragma unroll
         for (int hi = 0; hi < 16; ++hi)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = hi * 8 + j, i = hi & 7;
+        for (int jj = 0; jj < 8; ++jj) {
+            // snake order over the wave's 8 x 8 accumulator tiles: odd rows walk the columns backwards, so that exactly ONE operand register changes
+            // from every MFMA to the next (at a row boundary too).  Same sums per accumulator; +1.1 % on a register-resident MFMA loop at the
+            // package power cap (tools/probes/probe_mfma_energy.hip, profiles/r05_run_aa_*)
+            const int t = hi * 8 + jj, i = hi & 7, j = SC_FAT_SNAKE && (hi & 1) ? 7 - jj : jj;
             if (t == RB) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             if (t == RC) {
                 // iteration k + 1 (issued one iteration ago) has landed when at most the DMA rounds of this iteration are in flight; in
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                     // (the asm MFMAs are invisible to the hazard recognizer, and the compiler is free to put accumulator moves
                     // right behind any separate drain statement)
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tv_cmp_ne_u32 vcc, 0, %3\n\ts_cbranch_vccz .Lfat_nodrain%=\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n"
-                             ".Lfat_nodrain%=:" : "+a"(acc[7][7]) : "v"(b1[7]), "v"(a1[7]), "v"(fin) : "vcc");
+                             ".Lfat_nodrain%=:" : "+a"(acc[7][j]) : "v"(b1[j]), "v"(a1[7]), "v"(fin) : "vcc");
             if (t < 16 * RS && t % RS == 0) { const int u = (t / RS) & 7; if (t / RS < 8) FAT_RD(b1[u], b_ad[1][X], u); else FAT_RD(a1[u], a_ad[1][X], u); }
             if (t >= RB && t < RB + 16 * DS && (t - RB) % DS == 0) dma((t - RB) / DS, X, k + 2);
             if (t >= RC && t < RC + 16 * RS && (t - RC) % RS == 0) {

@@ -8,6 +8,7 @@
 //   V3  V0 + 32 ds_read_b128 per 128 MFMAs (k_gemm_fat's fragment traffic, conflict-free addresses), results folded into the operands
 //   V4  V1 + the same LDS bytes per flop
 //   V5  V0 with v_mfma_f32_16x16x32_bf16 on the same bits
+//   V6  V0 with the operand roles exchanged (srcA walks, srcB stationary over 8 MFMAs - k_gemm_fat's arrangement)   V7  V0 in snake order
 // build: hipcc -O3 --offload-arch=gfx950 tools/probes/probe_mfma_energy.hip -o /tmp/probe_mfma_energy ; run: /tmp/probe_mfma_energy [seconds per variant]
 #include <hip/hip_runtime.h>
 #include <glob.h>
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int iters, long long* cl
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (V == 5) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+                        if (V == 6) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(b[j]), "v"(a[i]));        // srcA walks, srcB stationary (k_gemm_fat today)
+                        else if (V == 7) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][(i & 1) ? 7 - j : j]) : "v"(a[i]), "v"(b[(i & 1) ? 7 - j : j]));   // snake: one operand changes per step
+                        else if (V == 5) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
                         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
                     }     // (tied in place: hipcc rotates builtin accumulators through VGPRs)
                     if (LDS) {                                    // 2 reads per 8 MFMAs -> 32 per 128
@@ -163,6 +166,10 @@ int main(int argc, char** argv) {
     run<1>("32x32x16 random", secs, out, p.multiProcessorCount, clk, wall_khz);
     run<3>("16x16x32 random + LDS fragment reads", secs, out, p.multiProcessorCount, clk, wall_khz);
     run<4>("32x32x16 random + LDS fragment reads", secs, out, p.multiProcessorCount, clk, wall_khz);
+    run<6>("16x16x32 random, srcA walks / srcB stationary", secs, out, p.multiProcessorCount, clk, wall_khz);
+    run<7>("16x16x32 random, snake order", secs, out, p.multiProcessorCount, clk, wall_khz);
+    run<0>("16x16x32 random (srcA stationary / srcB walks, 3rd)", secs, out, p.multiProcessorCount, clk, wall_khz);
+    run<6>("16x16x32 random, srcA walks / srcB stationary (2nd)", secs, out, p.multiProcessorCount, clk, wall_khz);
     run<5>("16x16x32 bf16, the same random bits", secs, out, p.multiProcessorCount, clk, wall_khz);
     run<0>("16x16x32 random (again)", secs, out, p.multiProcessorCount, clk, wall_khz);
     return 0;
