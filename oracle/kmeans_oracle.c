@@ -16,19 +16,26 @@
  *     C_{i+1} = C'                                                  :317
  *   return C, labels, W, i        (on exhaustion C is one update ahead of labels — Q3)
  *
- * Reduction spec "SC-KM1" (shared, bit for bit, with streamchat_amd/csrc/kmeans.hip so that
- * labels are identical by construction, ties included):
- *   - columns are cut into chunks of 512 = 64 lanes x 8 elements; lane l of chunk c owns columns
- *     c*512 + l*8 + e, e<8; columns >= D contribute 0.
- *   - lane partial: d = x - c (fp32); even e feed acc0 = fmaf(d,d,acc0), odd e feed acc1;
- *     p = acc0 + acc1.
- *   - wave partial: for h in 32,16,8,4,2,1: p[a] += p[a+h] (a<h), fp32.
- *   - total: chunks are cut into 32 contiguous segments of ceil(nchunks/32); each segment is summed
- *     in ascending chunk order in fp64, then the 32 segment sums are summed in ascending order.
+ * Reduction spec "SC-KM2" (round 6; shared, bit for bit, with streamchat_amd/csrc/kmeans.hip so that
+ * labels are identical by construction, ties included).  SC-KM1 (rounds 1-5) reduced every 512-column
+ * chunk with a 64-lane tree per (row, cluster): that tree is what kept a one-read Lloyd pass from
+ * fitting on chip with more than one wave per SIMD.  SC-KM2 keeps SC-KM1's cell (8
+ * columns, two fma chains) and replaces everything above it by a structure a thread that owns a ROW
+ * can compute alone (no cross-lane step), while a lane that owns COLUMNS still can (an 8- or 16-lane
+ * butterfly):
+ *   - cell    = 8 consecutive columns c*8 + e, e < 8; columns >= D contribute 0.
+ *               d = x - c (fp32); even e feed acc0 = fmaf(d,d,acc0), odd e feed acc1; p = acc0 + acc1.
+ *   - slice   = SC_SLICE (64) consecutive columns = SC_SLICE/8 cells; slice partial = adjacent-pair
+ *               tree over the cells: level j = 0,1,.. adds the partial of cell a + 2^j to cell a
+ *               (a a multiple of 2^(j+1)), fp32.
+ *   - group   = 2048 consecutive columns; group total = the group's slice partials added in ascending
+ *               order to 0.0 in fp64.
+ *   - total   = the groups are cut into 32 contiguous segments of ceil(ngroups/32); each segment is
+ *               summed in ascending group order in fp64, then the 32 segment sums in ascending order.
  *   - argmin on the fp64 totals (sqrt is monotone; first minimum wins).
  *   - update: per column, s = 0; for t in cluster (ascending): s = s + (w_t * x) in fp32 without
- *     fma contraction; C' = s / W (fp32 division).  W likewise sequential fp32.
- *   - shift: the same lane/wave/segment tree on (C_i - C')^2 per cluster, then
+ *     fma contraction; C' = s / W (fp32 division).  W likewise sequential fp32.  (unchanged)
+ *   - shift: the same cell / slice / group / segment structure on (C_i - C')^2 per cluster, then
  *     sum_k sqrt(total_k) in fp64, compared with (double)tol.
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC kmeans_oracle.c -o libsc_oracle.so -lm
@@ -38,7 +45,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define CH 512
+#ifndef SC_SLICE
+#define SC_SLICE 64             /* columns per slice (spec constant; kmeans.hip: KM_SW) */
+#endif
+#define SC_GROUP 2048           /* columns per fp64 group (spec constant; kmeans.hip: KM_GW) */
+#define NCELL (SC_SLICE / 8)
+#define NSL (SC_GROUP / SC_SLICE)
 #define NSEG 32
 
 static inline float h2f(uint16_t h) { /* IEEE binary16 -> binary32, exact */
@@ -59,66 +71,75 @@ static inline float ldx(const void *X, int dtype, size_t i) {
     return dtype == 0 ? h2f(v) : b2f(v);
 }
 
-static float wave_tree(float *p) {
-    for (int h = 32; h >= 1; h >>= 1)
-        for (int a = 0; a < h; ++a) p[a] = p[a] + p[a + h];
+/* adjacent-pair tree over the NCELL cell partials of a slice */
+static float slice_tree(float *p) {
+    for (int h = 1; h < NCELL; h <<= 1)
+        for (int a = 0; a < NCELL; a += 2 * h) p[a] = p[a] + p[a + h];
     return p[0];
 }
 
-/* fp32 wave partial of sum_j (a_j - b_j)^2 over chunk c; a/b fetched by callbacks on column index */
-static float chunk_partial_xc(const void *X, int dtype, size_t rowoff, const float *Crow, int64_t D, int64_t c) {
-    float p[64];
-    for (int l = 0; l < 64; ++l) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int e = 0; e < 8; ++e) {
-            int64_t col = c * CH + l * 8 + e;
-            float x = 0.f, cc = 0.f;
-            if (col < D) { x = ldx(X, dtype, rowoff + (size_t)col); cc = Crow[col]; }
-            float d = x - cc;
-            if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+/* fp64 group total of sum_j (x_j - c_j)^2 over group g of row `rowoff` */
+static double group_total_xc(const void *X, int dtype, size_t rowoff, const float *Crow, int64_t D, int64_t g) {
+    double tot = 0.0;
+    for (int s = 0; s < NSL; ++s) {
+        float p[NCELL];
+        for (int cl = 0; cl < NCELL; ++cl) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                int64_t col = g * SC_GROUP + (int64_t)s * SC_SLICE + cl * 8 + e;
+                float x = 0.f, cc = 0.f;
+                if (col < D) { x = ldx(X, dtype, rowoff + (size_t)col); cc = Crow[col]; }
+                float d = x - cc;
+                if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+            }
+            p[cl] = a0 + a1;
         }
-        p[l] = a0 + a1;
+        tot += (double)slice_tree(p);
     }
-    return wave_tree(p);
+    return tot;
 }
-static float chunk_partial_cc(const float *A, const float *B, int64_t D, int64_t c) {
-    float p[64];
-    for (int l = 0; l < 64; ++l) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int e = 0; e < 8; ++e) {
-            int64_t col = c * CH + l * 8 + e;
-            float d = 0.f;
-            if (col < D) d = A[col] - B[col];
-            if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+static double group_total_cc(const float *A, const float *B, int64_t D, int64_t g) {
+    double tot = 0.0;
+    for (int s = 0; s < NSL; ++s) {
+        float p[NCELL];
+        for (int cl = 0; cl < NCELL; ++cl) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                int64_t col = g * SC_GROUP + (int64_t)s * SC_SLICE + cl * 8 + e;
+                float d = 0.f;
+                if (col < D) d = A[col] - B[col];
+                if (e & 1) a1 = fmaf(d, d, a1); else a0 = fmaf(d, d, a0);
+            }
+            p[cl] = a0 + a1;
         }
-        p[l] = a0 + a1;
+        tot += (double)slice_tree(p);
     }
-    return wave_tree(p);
+    return tot;
 }
 
-static double seg_total(const float *wp, int64_t nch) { /* wp[nch] fp32 chunk partials -> fp64 two-level sum */
-    int64_t seglen = (nch + NSEG - 1) / NSEG;
+static double seg_total(const double *gp, int64_t ng) { /* gp[ng] fp64 group totals -> two-level sum */
+    int64_t seglen = (ng + NSEG - 1) / NSEG;
     double tot = 0.0;
     for (int s = 0; s < NSEG; ++s) {
         double a = 0.0;
-        int64_t lo = (int64_t)s * seglen, hi = lo + seglen; if (hi > nch) hi = nch;
-        for (int64_t c = lo; c < hi; ++c) a += (double)wp[c];
+        int64_t lo = (int64_t)s * seglen, hi = lo + seglen; if (hi > ng) hi = ng;
+        for (int64_t c = lo; c < hi; ++c) a += gp[c];
         tot += a;
     }
     return tot;
 }
 
-/* squared distances dist2[T*K] (fp64) of every row to every centroid, SC-KM1 order */
+/* squared distances dist2[T*K] (fp64) of every row to every centroid, SC-KM2 order */
 void sc_oracle_kmeans_dist2(const void *X, int dtype, int T, int64_t D, int K, const float *C, double *dist2) {
-    int64_t nch = (D + CH - 1) / CH;
+    int64_t nch = (D + SC_GROUP - 1) / SC_GROUP;
 #pragma omp parallel
     {
-        float *wp = (float *)malloc(sizeof(float) * (size_t)nch);
+        double *wp = (double *)malloc(sizeof(double) * (size_t)nch);
 #pragma omp for schedule(dynamic, 1) collapse(2)
         for (int t = 0; t < T; ++t)
             for (int k = 0; k < K; ++k) {
                 for (int64_t c = 0; c < nch; ++c)
-                    wp[c] = chunk_partial_xc(X, dtype, (size_t)t * (size_t)D, C + (size_t)k * D, D, c);
+                    wp[c] = group_total_xc(X, dtype, (size_t)t * (size_t)D, C + (size_t)k * D, D, c);
                 dist2[(size_t)t * K + k] = seg_total(wp, nch);
             }
         free(wp);
@@ -133,10 +154,10 @@ int sc_oracle_kmeans_fit(const void *X, int dtype, int T, int64_t D, int K, cons
                          float *C /*[K*D] out*/, int64_t *labels /*[T] out*/, float *wsum /*[K] out*/, int *iters,
                          int32_t *trace_labels) {
     if (T <= 0 || D <= 0 || K <= 0 || max_iter <= 0) return -1;
-    int64_t nch = (D + CH - 1) / CH;
+    int64_t nch = (D + SC_GROUP - 1) / SC_GROUP;
     float *Ccur = (float *)malloc(sizeof(float) * (size_t)K * D), *Cnew = (float *)malloc(sizeof(float) * (size_t)K * D);
     double *d2 = (double *)malloc(sizeof(double) * (size_t)T * K);
-    float *wp = (float *)malloc(sizeof(float) * (size_t)nch);
+    double *wp = (double *)malloc(sizeof(double) * (size_t)nch);
     int rpos = 0, rc = 0, i;
     for (int k = 0; k < K; ++k) {
         if (init_idx[k] < 0 || init_idx[k] >= T) { rc = -1; goto out; }
@@ -174,7 +195,7 @@ int sc_oracle_kmeans_fit(const void *X, int dtype, int T, int64_t D, int K, cons
         }
         double diff = 0.0;
         for (int k = 0; k < K; ++k) {
-            for (int64_t c = 0; c < nch; ++c) wp[c] = chunk_partial_cc(Ccur + (size_t)k * D, Cnew + (size_t)k * D, D, c);
+            for (int64_t c = 0; c < nch; ++c) wp[c] = group_total_cc(Ccur + (size_t)k * D, Cnew + (size_t)k * D, D, c);
             diff += sqrt(seg_total(wp, nch));
         }
         if (diff < (double)tol) break;

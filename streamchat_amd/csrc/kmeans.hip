@@ -3,29 +3,49 @@
 // D = 576*3584 = 2,064,384 features and K is tiny (5..8), so this is a pure streaming reduce:
 // the reference's [T,K,D] broadcast temporary (utiles.py:299, 8.3 GB at T=400) is never formed.
 //
-// Kernels (one Lloyd iteration = assign -> reduce -> labels/order -> update -> decide):
-//   km_assign   one wave per 512-column chunk; centroid slice lives in VGPRs, rows stream through
-//               as 16-byte/lane coalesced loads (1 KiB per wave-instruction); the TT*KB fp32 lane
-//               partials of a row group are reduced across the wave with a halving butterfly
-//               (v_permlane32_swap / v_permlane16_swap + 4 shuffle levels: ~2.5 ops per value
-//               instead of 12) and written as one coalesced 256-byte line per group.
-//   km_reduce   fp64 two-level (32 segments) sum of the per-chunk partials.
-//   km_argmin   fp64 totals -> argmin (first minimum), one thread per row.
-//   km_order    single block: stable counting sort of rows by label (ballot ranks), W[k], empty-cluster ranks.
-//   km_update   one wave per chunk: per cluster, rows in ascending order, fp32 sequential
-//               weighted sum / W; shift partials for the convergence test.
-//   km_decide   sum_k ||C_i - C'||_2 < tol ? -> device-side `done` flag (no host round trip).
-// The arithmetic order is the "SC-KM1" spec shared bit-for-bit with oracle/kmeans_oracle.c.
+// Reduction spec "SC-KM2" (round 6), shared bit for bit with oracle/kmeans_oracle.c:
+//   cell  = 8 columns: d = x - c, even / odd fma chains, p = acc0 + acc1          (what a LANE that owns 8 columns computes)
+//   slice = KM_SW columns: adjacent-pair tree over its cells                      (8- / 16-lane butterfly, or one THREAD that owns the row)
+//   group = 2048 columns: slice partials added in ascending order in fp64
+//   total = 32 contiguous segments of groups in fp64, then the segment sums; argmin = first minimum of the fp64 totals
+//   update sums: per column, rows of the cluster in ascending order, sequential fp32, no contraction; shift: the distance structure on (C - C')^2
+// SC-KM1 (rounds 1-5) had a 64-lane tree per (row, cluster, 512-column chunk); that tree is why the one-read pass of round 5 (km_fused) could
+// only hold its slab in the register file of ONE wave per SIMD and ran 1.6 - 2.2x slower than two passes.  Under SC-KM2 nothing above the
+// cell needs a cross-lane step when a thread owns a row, so the slab can live in LDS and the pass runs at normal occupancy.
+//
+// Two kernel families, same bits:
+//   km2_pass<K, NRB, Q, MODE>   (fp16 rows, D % KM_SW == 0, K in {5, 8}, T <= 448)   ONE read of X per Lloyd iteration.
+//               A workgroup owns a 2048-column group and walks its slices; the [T, KM_SW] fp16 slab of a slice is brought into LDS by
+//               LDS-DMA (buffer_load ... lds, swizzled on the source address) and used twice:
+//                 update   wave k = cluster k, lane = column: the cluster's rows in ascending order from LDS (one xor + ds_read + cvt + add
+//                          per row), C' = sum / W -> LDS + global; the shift partial by (k, cell) threads;
+//                 assign   (for the NEXT iteration, against C') lane = row: x from LDS as 16-byte reads, the centroid cell as SGPR operands
+//                          (s_load of the C' this workgroup just wrote: wave-uniform, so the packed fp32 ops take it straight from
+//                          SGPRs), the cell / slice tree in registers, fp64 group accumulators per thread.
+//               MODE 2 = assign only (iteration 0), 1 = update only (last iteration), 3 = both.
+//   km_assign / km_update        (any dtype, any D, K, T)   two passes over X per iteration; lane = 8 columns, rows streamed through registers.
+// Both are followed per iteration by km_reduce (segments) -> km_argmin -> km_order (stable counting sort, W[k], empty ranks) and km_decide
+// (sum_k ||C_i - C'||_2 < tol ? -> device-side `done` flag, no host round trip).
 // Compiled with -ffp-contract=off: every fma below is explicit.
 #include "sc_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
 
-constexpr int CH = 512;      // columns per chunk = 64 lanes x 8 elements
+#ifndef KM_SW
+#define KM_SW 64             // columns per slice (spec constant: oracle/kmeans_oracle.c SC_SLICE)
+#endif
+constexpr int CH = 512;      // columns per chunk of the lane-mapped kernels = 64 lanes x 8 elements
+constexpr int GW = 2048;     // columns per fp64 group (spec constant) = the 4 chunks of one workgroup
+constexpr int SW = KM_SW;
+constexpr int NCELL = SW / 8;            // cells per slice
+constexpr int NSL = GW / SW;             // slices per group
+constexpr int SPC = CH / SW;             // slices per chunk
 constexpr int NSEG = 32;     // fp64 segments
-constexpr int WPB = 4;       // waves per block in the streaming kernels (2 / 8: +-0.3 %, profiles/r04_run9_kmeans_knobs.md)
+constexpr int WPB = 4;       // waves per block in the lane-mapped kernels: one group
+static_assert(SW == 64 || SW == 128, "KM_SW");
 typedef float sc_f2 __attribute__((ext_vector_type(2)));
 
 struct KmState {
@@ -77,34 +97,40 @@ __device__ __forceinline__ void load8_guard(const void* base, size_t rowoff, int
     for (int e = 0; e < 8; ++e) o[e] = (col + e < D) ? sc_load1<Tag>(base, rowoff + (size_t)(col + e)) : 0.f;
 }
 
-template <int M>
-__device__ __forceinline__ void bfly_step(float (&v)[64], int lane) {
-    const bool up = (lane & M) != 0;
+// One level of the halving butterfly: the lanes that differ in bit log2(L) split the N live values between them - the lane with the bit
+// clear keeps v[0 .. N/2), the other v[N/2 .. N) (stored back at 0 .. N/2) - and each adds the partner's partial of the values it keeps.
+template <int L, int N>
+__device__ __forceinline__ void bfly_halve(float (&v)[64], int lane) {
+    const bool up = (lane & L) != 0;
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-        const float send = up ? v[i] : v[i + M];
-        const float keep = up ? v[i + M] : v[i];
-        v[i] = keep + __shfl_xor(send, M, 64);
+    for (int i = 0; i < N / 2; ++i) {
+        const float send = up ? v[i] : v[i + N / 2];
+        const float keep = up ? v[i + N / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, L, 64);
     }
 }
 
-// Halving butterfly: on entry lane L holds 64 values v[i] (item i, this lane's partial);
-// on exit v[0] of lane L holds the SC-KM1 tree sum over all 64 lanes of item L.
-__device__ __forceinline__ void butterfly64(float (&v)[64], int lane) {
+// SC-KM2 slice tree for 64 items at once: on entry lane L holds its cell partial v[i] of 64 items; on exit v[0 .. NV) (NV = 64 / NCELL)
+// hold, for the slice made of this lane's NCELL-lane row, the slice partials of the items
+//   item(i) = i + sum_b bit_b(lane) * (32 >> b),  b < log2(NCELL)
+// (levels = lane bits 0, 1, 2(, 3): adjacent-pair order).  ~1.9 ops per value.
+constexpr int NV = 64 / NCELL;
+__device__ __forceinline__ void butterfly_slice(float (&v)[64], int lane) {
+    bfly_halve<1, 64>(v, lane);
+    bfly_halve<2, 32>(v, lane);
+    bfly_halve<4, 16>(v, lane);
+    if (NCELL == 16) bfly_halve<8, 8>(v, lane);
+}
+__device__ __forceinline__ int butterfly_item(int i, int lane) {
+    int it = i + (lane & 1) * 32 + ((lane >> 1) & 1) * 16 + ((lane >> 2) & 1) * 8;
+    if (NCELL == 16) it += ((lane >> 3) & 1) * 4;
+    return it;
+}
+// slice partial of one value per lane (a cell partial): every lane of the NCELL-lane row returns the row's tree sum
+__device__ __forceinline__ float slice_tree_sum(float v) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    bfly_step<8>(v, lane);
-    bfly_step<4>(v, lane);
-    bfly_step<2>(v, lane);
-    bfly_step<1>(v, lane);
+    for (int m = 1; m < NCELL; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
 }
 
 __host__ __device__ constexpr int tt_for(int kb) { return (64 / kb) < 16 ? (64 / kb) : 16; }
@@ -113,14 +139,14 @@ __host__ __device__ constexpr int tt_for(int kb) { return (64 / kb) < 16 ? (64 /
 template <typename Tag, int KB, bool VEC>
 __global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X, const float* __restrict__ Ca,
                                                       const float* __restrict__ Cb, const KmState* __restrict__ st,
-                                                      float* __restrict__ partial, int T, int64_t D, int K, int k0,
+                                                      double* __restrict__ gpart, int T, int64_t D, int K, int k0,
                                                       int64_t nchunks) {
     constexpr int TT = tt_for(KB);
     if (st->done) return;
+    __shared__ float sl[64][NSL + 1];                  // slice partials of the row group's 64 items over the NSL slices of this workgroup's group
     const float* __restrict__ C = st->cur ? Cb : Ca;
-    const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (c >= nchunks) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * WPB + wave;           // (a chunk past the end contributes zeros: its waves still join the barriers)
     const int64_t col = c * CH + lane * 8;
     const bool active = col < D;
     const size_t I = (size_t)T * (size_t)K;
@@ -185,12 +211,22 @@ __global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X
                 p[tt * KB + k] = acc.x + acc.y;
             }
         }
-        butterfly64(p, lane);
-        if (lane < TT * KB) {
-            const int tt = lane / KB, k = lane - tt * KB;
-            const int t = g * TT + tt;
-            if (t < T) partial[(size_t)c * I + (size_t)t * K + (k0 + k)] = p[0];
+        butterfly_slice(p, lane);
+        {
+            const int sidx = wave * SPC + lane / NCELL;           // slice of the group
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sl[butterfly_item(i, lane)][sidx] = p[i];
         }
+        __syncthreads();
+        if (threadIdx.x < TT * KB) {                              // group total of one item: its NSL slice partials in ascending order, fp64
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < NSL; ++q) a += (double)sl[threadIdx.x][q];
+            const int tt = threadIdx.x / KB, k = threadIdx.x - tt * KB;
+            const int t = g * TT + tt;
+            if (t < T) gpart[(size_t)blockIdx.x * I + (size_t)t * K + (k0 + k)] = a;
+        }
+        __syncthreads();
         if (VEC) {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) cur[tt] = nxt[tt];
@@ -198,8 +234,8 @@ __global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X
     }
 }
 
-// level-1 fp64 reduce: seg[s][item] = sum_{c in segment s, ascending} partial[c][item]
-__global__ void km_reduce(const float* __restrict__ partial, const KmState* __restrict__ st, double* __restrict__ seg,
+// level-1 fp64 reduce: seg[s][item] = sum_{g in segment s, ascending} gpart[g][item]
+__global__ void km_reduce(const double* __restrict__ partial, const KmState* __restrict__ st, double* __restrict__ seg,
                           size_t I, int64_t nchunks, int check_done) {
     if (check_done && st->done) return;
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,13 +247,13 @@ __global__ void km_reduce(const float* __restrict__ partial, const KmState* __re
     double a = 0.0;
     int64_t c = lo;
     for (; c + 8 <= hi; c += 8) {
-        float v[8];
+        double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + u) * I + item];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += (double)v[u];
+        for (int u = 0; u < 8; ++u) a += v[u];
     }
-    for (; c < hi; ++c) a += (double)partial[(size_t)c * I + item];
+    for (; c < hi; ++c) a += partial[(size_t)c * I + item];
     seg[(size_t)s * I + item] = a;
 }
 
@@ -312,13 +348,13 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
                                                       const int* __restrict__ order, const int* __restrict__ start,
                                                       const float* __restrict__ W, const int* __restrict__ empty_rank,
                                                       const int* __restrict__ reseed_idx, int n_reseed,
-                                                      float* __restrict__ dpart, int T, int64_t D, int K, int64_t nchunks, int empty_zero) {
+                                                      double* __restrict__ dgpart, int T, int64_t D, int K, int64_t nchunks, int empty_zero) {
     if (st->done) return;
+    extern __shared__ float sh[];                      // [K][NSL] slice partials of the shift over this workgroup's group
     const float* __restrict__ Cold = st->cur ? Cb : Ca;
     float* __restrict__ Cnew = st->cur ? Ca : Cb;
-    const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (c >= nchunks) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * WPB + wave;           // (a chunk past the end contributes zeros and still joins the barrier)
     const int64_t col = c * CH + lane * 8;
     const bool active = col < D;
     const int rbase = st->reseed_pos;
@@ -389,8 +425,8 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
             a0 = __builtin_fmaf(d0, d0, a0);
             a1 = __builtin_fmaf(d1, d1, a1);
         }
-        const float wp = sc_wave_tree_sum(a0 + a1);
-        if (lane == 0) dpart[(size_t)c * K + k] = wp;
+        const float sp = slice_tree_sum(a0 + a1);
+        if (lane % NCELL == 0) sh[k * NSL + wave * SPC + lane / NCELL] = sp;
         if (VEC) {
             if (active) {
                 sc_f4* dst = reinterpret_cast<sc_f4*>(Cnew + (size_t)k * (size_t)D + (size_t)col);
@@ -403,261 +439,235 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
                 if (col + e < D) Cnew[(size_t)k * (size_t)D + (size_t)(col + e)] = cn[e];
         }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {            // group total: slice partials in ascending order, fp64
+        double a = 0.0;
+        for (int q = 0; q < NSL; ++q) a += (double)sh[k * NSL + q];
+        dgpart[(size_t)blockIdx.x * K + k] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 5: update(i) + assign(i + 1) in ONE pass over X (fp16, D % 512 == 0, K <= 8, T <= 8 * RW).
-// km_assign and km_update each stream the whole [T, D] matrix: 2 n reads of X for n Lloyd iterations, 0.77 ms per iteration at T = 400,
-// K = 5, D = 2 064 384 against 0.27 ms for one read at the HBM rate.  Both need the chunk's T x 1 KiB slab; what stops a single pass is
-// where to keep 400 KiB between the two uses.  Here a persistent workgroup of EIGHT waves (two per SIMD, 256 registers each) keeps the
-// slab of one 512-column chunk IN REGISTERS - wave w owns rows [w RW, (w + 1) RW) as the raw 16 bytes per lane and row, 4 VGPRs each,
-// 200 of its 256 registers at RW = 50 - and walks chunks c = b, b + G, ...:
-//   update   SC-KM1 adds a cluster's rows in ascending order, one fp32 accumulator per column: the sum of cluster k travels through the
-//            waves in row order as a systolic chain - in phase p wave w adds its rows of cluster p - w to the running sums in LDS
-//            (K + 7 phases, one barrier each); which rows those are is a 64-bit ballot mask per cluster, built once per launch;
-//   finish   wave k divides cluster k by W_k (or takes the reseed row), writes C', the shift partial of the chunk and the new centroid
-//            slice into LDS;
-//   assign   every wave takes its rows once more - still in registers - against the K new slices (LDS): the lane partials of a row's K
-//            distances are reduced with an 8-value halving butterfly (levels 32, 16, 8 halve the values, 4, 2, 1 are plain xor-adds: the
-//            SC-KM1 tree, 8 live registers instead of butterfly64's 64);
-//   reload   the registers of row j are free the moment its distances are done: the row of the NEXT chunk is requested right there, so the
-//            stream runs under the whole assign pass and the next update finds its slab (mostly) landed.
-// One read of X per Lloyd iteration (n + 1 for n iterations with the plain first assign).  Arithmetic order is SC-KM1 throughout: labels,
-// centroids and exit iteration stay bit-identical to the two-kernel path and to oracle/kmeans_oracle.c.
+// Round 6: update(i) + assign(i + 1) in ONE pass over X from an LDS-resident slab (see the header).  fp16 rows, D % KM_SW == 0.
 // ---------------------------------------------------------------------------------------------
-constexpr int FNW = 4;                                                        // waves per workgroup of the fused pass: one per SIMD, 512 registers each
-
-// (the empty asm makes the conversion depend on THIS point of the program: without it hipcc hoists the unpacking of every row out of the
-//  phase loop - 8 fp32 registers per row live across it, the slab's footprint tripled and spilled)
-__device__ __forceinline__ void unpack_h8(uint4& a, float (&o)[8]) {
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-    const sc_h8 v = __builtin_bit_cast(sc_h8, a);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
-}
-
-// First half of the SC-KM1 wave tree for 8 values per lane (this lane's partials of items 0..7): the levels 32, 16, 8 halve the values;
-// on return the lane holds ONE value: the partial of item (lane >> 3) over the lanes that differ from it in bits 5, 4, 3.
-__device__ __forceinline__ float butterfly8_hi(float (&v)[8], int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                                             // lanes ^ 32: items i | i + 4
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                                             // lanes ^ 16: items i | i + 2
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    const bool up = (lane & 8) != 0;                                          // lanes ^ 8: items 0 | 1
-    const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
-    return keep + __shfl_xor(send, 8, 64);
-}
-
-// compile-time row loops (a `#pragma unroll` over 100 rows is refused by the unroller's budget, and raising the budget unrolls every other loop
-// of the kernel too - 300 k instructions; a recursive template is unrolled by construction and nothing else is)
+// compile-time loops (a recursive template is unrolled by construction, whatever the unroller's budget says)
 template <int J, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
 }
 
-template <int RW, int K, bool ASSIGN>                                         // rows per wave, clusters, whether the next iteration's partials are wanted
-__global__ __launch_bounds__(FNW * 64) void km_fused(const _Float16* __restrict__ X, float* __restrict__ Ca, float* __restrict__ Cb,
-                                                     const KmState* __restrict__ st, const float* __restrict__ w,
-                                                     const int* __restrict__ labels32, const float* __restrict__ W,
-                                                     const int* __restrict__ empty_rank, const int* __restrict__ reseed_idx, int n_reseed,
-                                                     float* __restrict__ dpart, float* __restrict__ partial, int T, int64_t D,
-                                                     int64_t nchunks) {
-    if (st->done) return;
-    constexpr int NM = (RW + 63) / 64;                                        // 64-row mask words per cluster
-    constexpr int GR = 4, NG = (RW + GR - 1) / GR;                            // rows whose butterflies interleave in the assign pass (8: 130 - 290 spilled registers)
-    __shared__ __attribute__((aligned(16))) float sums[K][CH];               // running column sums per cluster (the chain), then the new slices
-    const float* __restrict__ Cold = st->cur ? Cb : Ca;
-    float* __restrict__ Cnew = st->cur ? Ca : Cb;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r0 = wave * RW;
-    const int rbase = st->reseed_pos;
-    const size_t I = (size_t)T * (size_t)K;
-    // which of this wave's rows belong to cluster k: lane l of mask word m stands for row r0 + 64 m + l
-    unsigned long long mask[K][NM], live[NM];
-    float myw[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int jr = 64 * m + lane, myrow = r0 + jr;
-        const bool ok = jr < RW && myrow < T;
-        const int mylab = ok ? labels32[myrow] : -1;
-        myw[m] = (w && ok) ? w[myrow] : 1.0f;
-        live[m] = __ballot(ok);
-#pragma unroll
-        for (int k = 0; k < K; ++k) mask[k][m] = __ballot(mylab == k);
-    }
+// 16-byte LDS-DMA through a raw buffer resource: lane l's 16 bytes land at lds + 16 l
+__device__ __forceinline__ void km2_dma16(const void* base, unsigned extent, char* lds, unsigned voff, unsigned soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)extent, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+// v + (v of the lane a DPP control selects): one v_add_f32_dpp
+template <int CTRL>
+__device__ __forceinline__ float km2_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 
-    uint4 row[RW];
-    // one running pointer per load sweep (rows are consecutive; past T it stops advancing: the last row is re-read and never used) - a
-    // hundred precomputed row addresses are two hundred live scalars
-    const size_t row_first = (size_t)(r0 < T ? r0 : T - 1) * (size_t)D + (size_t)lane * 8;
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    int64_t c = blockIdx.x;
-    if (c >= nchunks) return;
-    {
-        const _Float16* xp = X + (size_t)c * CH + row_first;
-        static_for<0, RW>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(xp));
-            row[j] = make_uint4(v[0], v[1], v[2], v[3]);
-            if (r0 + j + 1 < T) xp += D;
-        });
+constexpr int KM2_NW = 8;                                                     // waves per workgroup
+constexpr int KM2_ROWB = SW * 2;                                              // bytes per slab row
+__host__ __device__ constexpr size_t km2_lds_bytes(int K, int RGW) { return (size_t)RGW * 64 * KM2_ROWB + (size_t)K * SW * 4; }
+// waves per SIMD the register allocation must leave room for: as many workgroups as the LDS admits on a CU (at most 32 waves), over 4 SIMDs
+__host__ __device__ constexpr int km2_min_waves_per_simd(int K, int RGW) {
+    int wgs = (int)((160 * 1024) / km2_lds_bytes(K, RGW));
+    if (wgs * KM2_NW > 32) wgs = 32 / KM2_NW;
+    if (wgs < 1) wgs = 1;
+    const int wps = wgs * KM2_NW / 4;
+    return wps > 4 ? 4 : wps;                                                 // (128 registers: the K = 8 centroid cells alone take 64)
+}
+
+// K clusters; RGW = 8-row groups per wave (the slab holds RGW * 64 rows >= T); MODE 1 = update, 2 = assign, 3 = both.
+//   slab      [RGW * 64][64] fp16, row-major, one 128-byte line per row: a DMA instruction brings 8 rows (1 KiB, lane-linear)
+//   update    wave k < K: lane = column; row r of the cluster is one 2-byte LDS read at r * 128 + 2 lane (a whole line per instruction)
+//   assign    lane = (row r8 = lane / 8 of an 8-row group, cell = lane % 8): the group's 1 KiB is read lane-linear (16 bytes per lane), the K
+//             centroid cells of the lane's cell sit in 8 K registers for the whole slice; cell partial in the lane, slice tree = three DPP adds
+//             across the 8 cell lanes (quad_perm 1-0-3-2, 2-3-0-1, row_half_mirror: pairs (a, a^1), (a, a^2), then the two halves - the
+//             adjacent-pair tree); lane (r8, cell = k) keeps the fp64 group total of (row, k).
+template <int K, int RGW, int MODE>
+__global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void km2_pass(
+        const _Float16* __restrict__ X, float* Ca, float* Cb, const KmState* __restrict__ st, const float* __restrict__ w,
+        const int* __restrict__ order, const int* __restrict__ start, const float* __restrict__ W, const int* __restrict__ empty_rank,
+        const int* __restrict__ reseed_idx, int n_reseed, double* __restrict__ dgpart, double* __restrict__ gpart, int T, int64_t D) {
+    static_assert(SW == 64 && NCELL == 8 && K <= 8, "km2_pass is written for 64-column slices");
+    constexpr bool UPD = (MODE & 1) != 0, ASG = (MODE & 2) != 0;
+    constexpr int NW = KM2_NW, ROWS = RGW * 64;
+    constexpr int NCH = RGW;                                                  // 64-row chunks of a cluster's row list (a cluster has at most ROWS rows)
+    constexpr int UB = 8;                                                     // rows whose LDS reads are in flight together in the update
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const slab = smem;
+    float* const cnew = reinterpret_cast<float*>(smem + (size_t)ROWS * KM2_ROWB);
+    const float* Cold = st->cur ? Cb : Ca;
+    float* Cnew = st->cur ? Ca : Cb;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cell = lane & 7, r8 = lane >> 3;
+    const int64_t g = blockIdx.x;
+    const int64_t gcol = g * GW;
+    const int nsl = (int)((D - gcol) / SW < NSL ? (D - gcol) / SW : NSL);     // slices of this group (the last group may be short)
+    const unsigned extent = (unsigned)((size_t)T * (size_t)D * 2);
+    const unsigned rowbytes = (unsigned)(D * 2);
+    const int rbase = UPD ? st->reseed_pos : 0;
+
+    // update: wave k's list of the rows of cluster k (ascending) as LDS row offsets, lane-distributed, and their weights
+    unsigned prow[NCH];
+    float pwt[NCH];
+    int pcnt = 0;
+    if constexpr (UPD) {
+        if (wv < K) {
+            const int lo = start[wv], hi = start[wv + 1];
+            pcnt = hi - lo;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int i = lo + 64 * c + lane;
+                const int r = i < hi ? order[i] : 0;
+                prow[c] = (unsigned)r * KM2_ROWB;
+                pwt[c] = (w && i < hi) ? w[r] : 1.0f;
+            }
+        }
     }
+    double acc64[RGW];
+#pragma unroll
+    for (int n = 0; n < RGW; ++n) acc64[n] = 0.0;
+    double dsh = 0.0;                                                         // thread (k, cell 0): shift total of cluster k over the group
+    const int sk = threadIdx.x / NCELL, scell = threadIdx.x % NCELL;          // (cluster, cell) of the shift threads
+
 #pragma unroll 1
-    for (; c < nchunks; c += gridDim.x) {
-        const int64_t cn_next = c + gridDim.x;
-        const int64_t col = c * CH + lane * 8;
-        // ---- update: the ordered row sums as a chain through the waves ----
-#pragma unroll 1
-        for (int p = 0; p < K + FNW - 1; ++p) {
-            const int k = p - wave;
-            if (k >= 0 && k < K) {
-                float sacc[8];
-                if (wave == 0) {
+    for (int sidx = 0; sidx < nsl; ++sidx) {
+        const int64_t col0 = gcol + (int64_t)sidx * SW;
+        // ---- A: the slab of this slice -> LDS (rows >= T read as zeros: out of the buffer's range) ----
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sacc[e] = 0.f;
-                } else {
-                    const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
+        for (int ii = 0; ii < RGW; ++ii) {
+            const int i = wv + ii * NW;                                       // 8-row group
+            km2_dma16(X, extent, slab + i * 1024, (unsigned)(i * 8 + r8) * rowbytes + (unsigned)(cell << 4), (unsigned)(col0 * 2));
+        }
+        float co[8];                                                          // the old centroid cell of the shift threads
+        float cr[K][8];                                                       // assign: the K centroid cells of this lane's cell
+        if (UPD && threadIdx.x < K * NCELL) sc_load8<ScF32>(Cold, (size_t)sk * (size_t)D + (size_t)col0 + (size_t)scell * 8, co);
+        if constexpr (ASG && !UPD) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { sacc[e] = a[e]; sacc[4 + e] = b[e]; }
-                }
-                unsigned long long mk[NM];
+            for (int k = 0; k < K; ++k) sc_load8<ScF32>(Cold, (size_t)k * (size_t)D + (size_t)col0 + (size_t)cell * 8, cr[k]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- B: update - wave k owns cluster k, lane = column; the cluster's rows in ascending order ----
+        if constexpr (UPD) {
+            if (wv < K) {
+                const int k = wv;
+                const float Wk = W[k];
+                const unsigned lanebits = (unsigned)lane * 2u;
+                float cn = 0.f;
+                if (Wk > 0.f) {
+                    static_for<0, NCH>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        const int n = pcnt - 64 * c < 64 ? pcnt - 64 * c : 64;              // rows of the cluster in this chunk of its list (wave-uniform)
+                        int j = 0;
+                        for (; j + UB <= n; j += UB) {
+                            float xv[UB], wt[UB];
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {                                // mask[k] with a run-time k: a select chain over K scalar pairs
-                    mk[m] = 0;
+                            for (int u = 0; u < UB; ++u) {
+                                const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)prow[c], j + u);
+                                wt[u] = w ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt[c]), j + u)) : 1.0f;
+                                xv[u] = (float)*reinterpret_cast<const _Float16*>(slab + (so + lanebits));
+                            }
 #pragma unroll
-                    for (int kk = 0; kk < K; ++kk) mk[m] = (k == kk) ? mask[kk][m] : mk[m];
-                }
-                static_for<0, RW>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    __builtin_amdgcn_sched_barrier(0);                        // (one row at a time: interleaved, the unrolled rows' temporaries spill the slab)
-                    if ((mk[j >> 6] >> (j & 63)) & 1ull) {                    // (wave-uniform)
-                        float x[8];
-                        unpack_h8(row[j], x);
-                        if (w) {
-                            const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myw[j >> 6]), j & 63));
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) sacc[e] = sacc[e] + wt * x[e];        // mul, then add (no contraction: -ffp-contract=off)
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) sacc[e] = sacc[e] + x[e];
+                            for (int u = 0; u < UB; ++u) cn = w ? cn + wt[u] * xv[u] : cn + xv[u];      // mul, then add (no contraction: -ffp-contract=off)
                         }
-                    }
-                });
-                *reinterpret_cast<sc_f4*>(&sums[k][lane * 8]) = sc_f4{sacc[0], sacc[1], sacc[2], sacc[3]};
-                *reinterpret_cast<sc_f4*>(&sums[k][lane * 8 + 4]) = sc_f4{sacc[4], sacc[5], sacc[6], sacc[7]};
+                        for (; j < n; ++j) {
+                            const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)prow[c], j);
+                            const float x = (float)*reinterpret_cast<const _Float16*>(slab + (so + lanebits));
+                            if (w) cn = cn + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt[c]), j)) * x;
+                            else cn = cn + x;
+                        }
+                    });
+                    cn = cn / Wk;
+                } else {                                                      // empty cluster: the reseed row (it is in the slab like every row)
+                    const int pos = rbase + empty_rank[k];
+                    int r = 0;
+                    if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
+                    if (r < 0 || r >= T) r = 0;
+                    cn = (float)*reinterpret_cast<const _Float16*>(slab + ((unsigned)r * KM2_ROWB + lanebits));
+                }
+                cnew[k * SW + lane] = cn;
+                Cnew[(size_t)k * (size_t)D + (size_t)col0 + (size_t)lane] = cn;
             }
             __syncthreads();
-        }
-        // ---- finish: wave k % 4 owns cluster k: C' = sums / W (or the reseed row), shift partial, global store; the new slice replaces the sums ----
-#pragma unroll 1
-        for (int k = wave; k < K; k += FNW) {
-            float cn[8];
-            const float Wk = W[k];
-            if (Wk > 0.f) {
-                const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
+            // ---- C: shift partial of the slice, one thread per (cluster, cell) ----
+            if (wv < (K * NCELL + 63) / 64) {
+                float a0 = 0.f, a1 = 0.f;
+                if (threadIdx.x < K * NCELL) {
+                    const sc_f4 n0 = *reinterpret_cast<const sc_f4*>(cnew + sk * SW + scell * 8), n1 = *reinterpret_cast<const sc_f4*>(cnew + sk * SW + scell * 8 + 4);
+                    const float cnv[8] = {n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { cn[e] = a[e] / Wk; cn[4 + e] = b[e] / Wk; }
-            } else {
-                const int pos = rbase + empty_rank[k];
-                int r = 0;
-                if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
-                if (r < 0 || r >= T) r = 0;
-                sc_load8<ScF16>(X, (size_t)r * (size_t)D + (size_t)col, cn);
+                    for (int e = 0; e < 8; e += 2) {
+                        const float d0 = co[e] - cnv[e], d1 = co[e + 1] - cnv[e + 1];
+                        a0 = __builtin_fmaf(d0, d0, a0);
+                        a1 = __builtin_fmaf(d1, d1, a1);
+                    }
+                }
+                const float sp = slice_tree_sum(a0 + a1);
+                if (threadIdx.x < K * NCELL && scell == 0) dsh += (double)sp;
             }
-            float co[8];
-            sc_load8<ScF32>(Cold, (size_t)k * (size_t)D + (size_t)col, co);
-            float a0 = 0.f, a1 = 0.f;
+            if constexpr (ASG) {                                              // the new centroid cells of this lane's cell
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float d0 = co[e] - cn[e], d1 = co[e + 1] - cn[e + 1];
-                a0 = __builtin_fmaf(d0, d0, a0);
-                a1 = __builtin_fmaf(d1, d1, a1);
-            }
-            const float wp = sc_wave_tree_sum(a0 + a1);
-            if (lane == 0) dpart[(size_t)c * K + k] = wp;
-            sc_f4* dst = reinterpret_cast<sc_f4*>(Cnew + (size_t)k * (size_t)D + (size_t)col);
-            dst[0] = sc_f4{cn[0], cn[1], cn[2], cn[3]};
-            dst[1] = sc_f4{cn[4], cn[5], cn[6], cn[7]};
-            *reinterpret_cast<sc_f4*>(&sums[k][lane * 8]) = sc_f4{cn[0], cn[1], cn[2], cn[3]};
-            *reinterpret_cast<sc_f4*>(&sums[k][lane * 8 + 4]) = sc_f4{cn[4], cn[5], cn[6], cn[7]};
-        }
-        __syncthreads();
-        // ---- assign for the next iteration (against C', held in registers: 8 x K) + rolling reload of the slab for the next chunk ----
-        float cr[K][8];
-        if (ASSIGN) {
+                for (int k = 0; k < K; ++k) {
+                    const sc_f4 n0 = *reinterpret_cast<const sc_f4*>(cnew + k * SW + cell * 8), n1 = *reinterpret_cast<const sc_f4*>(cnew + k * SW + cell * 8 + 4);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const sc_f4 a = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8]), b = *reinterpret_cast<const sc_f4*>(&sums[k][lane * 8 + 4]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { cr[k][e] = a[e]; cr[k][4 + e] = b[e]; }
+                    for (int e = 0; e < 4; ++e) { cr[k][e] = n0[e]; cr[k][4 + e] = n1[e]; }
+                }
             }
         }
-        const bool more = cn_next < nchunks;                                  // (wave-uniform)
-        const _Float16* xn = X + (size_t)(more ? cn_next : c) * CH + row_first;
-        static_for<0, NG>([&](auto gc) {
-            constexpr int j0 = decltype(gc)::value * GR;
-            __builtin_amdgcn_sched_barrier(0);                                // (GR rows at a time: their butterflies interleave, the rest of the slab stays put)
-            float half[GR];                                                   // per row: the value left after the levels 32, 16, 8
-            static_for<0, GR>([&](auto jjc) {
-                constexpr int jj = decltype(jjc)::value, j = j0 + jj;
-                half[jj] = 0.f;
-                if constexpr (j < RW) {
+        // ---- D: assign - lane (r8, cell) of 8-row group i = wv + ii NW ----
+        if constexpr (ASG) {
+            static_for<0, RGW>([&](auto ic) {
+                constexpr int ii = decltype(ic)::value;
+                const int i = wv + ii * NW;
+                if (i * 8 < T) {                                              // (wave-uniform)
+                    const sc_h8 v = *reinterpret_cast<const sc_h8*>(slab + i * 1024 + lane * 16);
                     float x[8];
-                    if (ASSIGN) unpack_h8(row[j], x);
-                    if (more) {                                               // the registers of row j are free: next chunk's row j
-                        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(xn));
-                        row[j] = make_uint4(v[0], v[1], v[2], v[3]);
-                        if (r0 + j + 1 < T) xn += D;
-                    }
-                    if (ASSIGN) {
-                        float pv[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) pv[k] = 0.f;
+                    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+                    float mine = 0.f;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            sc_f2 acc = {0.f, 0.f};
+                    for (int k = 0; k < K; ++k) {
+                        sc_f2 acc = {0.f, 0.f};
 #pragma unroll
-                            for (int e = 0; e < 8; e += 2) {
-                                const sc_f2 xv = {x[e], x[e + 1]}, cv = {cr[k][e], cr[k][e + 1]};
-                                const sc_f2 d = xv - cv;
-                                acc = __builtin_elementwise_fma(d, d, acc);
-                            }
-                            pv[k] = acc.x + acc.y;
+                        for (int e = 0; e < 8; e += 2) {
+                            const sc_f2 xv = {x[e], x[e + 1]}, c2 = {cr[k][e], cr[k][e + 1]};
+                            const sc_f2 d = xv - c2;
+                            acc = __builtin_elementwise_fma(d, d, acc);
                         }
-                        half[jj] = butterfly8_hi(pv, lane);
+                        float p = acc.x + acc.y;                              // cell partial
+                        p = km2_dpp_add<0xB1>(p);                             // + cell ^ 1   (quad_perm [1,0,3,2])
+                        p = km2_dpp_add<0x4E>(p);                             // + pair ^ 2   (quad_perm [2,3,0,1])
+                        p = km2_dpp_add<0x141>(p);                            // + the other half of the 8 (row_half_mirror)
+                        mine = (cell == k) ? p : mine;
                     }
+                    acc64[ii] += (double)mine;
                 }
             });
-            if (ASSIGN) {
-                // second half of the tree (levels 4, 2, 1: plain xor-adds), the eight rows' chains interleaved
+            __syncthreads();                                                  // the slab is rewritten by the next slice's DMA
+        }
+    }
+    if constexpr (ASG) {
+        const size_t I = (size_t)T * K;
 #pragma unroll
-                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 4, 64);
-#pragma unroll
-                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 2, 64);
-#pragma unroll
-                for (int jj = 0; jj < GR; ++jj) half[jj] = half[jj] + __shfl_xor(half[jj], 1, 64);
-                const int k = lane >> 3;
-#pragma unroll
-                for (int jj = 0; jj < GR; ++jj) {
-                    const int j = j0 + jj;
-                    if (j < RW && ((live[j >> 6] >> (j & 63)) & 1ull) && (lane & 7) == 0 && k < K) partial[(size_t)c * I + (size_t)(r0 + j) * K + k] = half[jj];
-                }
-            }
-        });
-        __syncthreads();                                                      // `sums` is rewritten by the next chunk
+        for (int ii = 0; ii < RGW; ++ii) {
+            const int row = (wv + ii * NW) * 8 + r8;
+            if (cell < K && row < T) gpart[(size_t)g * I + (size_t)row * K + cell] = acc64[ii];
+        }
+    }
+    if constexpr (UPD) {
+        if (threadIdx.x < K * NCELL && scell == 0) dgpart[(size_t)g * K + sk] = dsh;
     }
 }
 
-// per-cluster squared shift totals ||C_k - C'_k||^2 of clusters [kb, kb + kn) from the per-chunk partials (SC-KM1: 32 contiguous chunk
-// segments in fp64, then the segment sums in fp64); result in tot[0..kn) (shared), valid after the trailing barrier
-__device__ __forceinline__ void km_shift_totals(const float* __restrict__ dpart, int K, int kb, int kn, int64_t nchunks, double* segs, double* tot) {
+// per-cluster squared shift totals ||C_k - C'_k||^2 of clusters [kb, kb + kn) from the fp64 group totals (SC-KM2: 32 contiguous group
+// segments, then the segment sums); result in tot[0..kn) (shared), valid after the trailing barrier.  (`nchunks` = number of groups)
+__device__ __forceinline__ void km_shift_totals(const double* __restrict__ dpart, int K, int kb, int kn, int64_t nchunks, double* segs, double* tot) {
     const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
     for (int p = threadIdx.x; p < NSEG * kn; p += blockDim.x) {
         const int s = p / kn, k = kb + p % kn;
@@ -665,14 +675,14 @@ __device__ __forceinline__ void km_shift_totals(const float* __restrict__ dpart,
         if (hi > nchunks) hi = nchunks;
         double a = 0.0;
         int64_t c = lo;
-        for (; c + 8 <= hi; c += 8) {                 // 8 independent loads in flight, added in ascending chunk order
-            float v[8];
+        for (; c + 8 <= hi; c += 8) {                 // 8 independent loads in flight, added in ascending group order
+            double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = dpart[(size_t)(c + u) * K + k];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += (double)v[u];
+            for (int u = 0; u < 8; ++u) a += v[u];
         }
-        for (; c < hi; ++c) a += (double)dpart[(size_t)c * K + k];
+        for (; c < hi; ++c) a += dpart[(size_t)c * K + k];
         segs[s * 64 + (k - kb)] = a;
     }
     __syncthreads();
@@ -685,7 +695,7 @@ __device__ __forceinline__ void km_shift_totals(const float* __restrict__ dpart,
 }
 
 // single block: shift = sum_k sqrt(total_k); decide convergence; advance state
-__global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart, KmState* __restrict__ st, int K, int64_t nchunks,
+__global__ __launch_bounds__(256) void km_decide(const double* __restrict__ dpart, KmState* __restrict__ st, int K, int64_t nchunks,
                                                  int iter, int max_iter, float tol, int n_reseed) {
     if (st->done) return;
     __shared__ double segs[NSEG * 64];   // K <= 64 per pass
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(256) void km_decide(const float* __restrict__ dpart
 }
 
 // single block: shift2[k] = ||C_k - C'_k||^2 (fp64) for the caller of sc_kmeans_update; W -> wsum
-__global__ __launch_bounds__(256) void km_shift_out(const float* __restrict__ dpart, const float* __restrict__ W, double* __restrict__ shift2,
+__global__ __launch_bounds__(256) void km_shift_out(const double* __restrict__ dpart, const float* __restrict__ W, double* __restrict__ shift2,
                                                     float* __restrict__ wsum, int K, int64_t nchunks) {
     __shared__ double segs[NSEG * 64];
     __shared__ double tot[64];
@@ -784,11 +794,11 @@ __global__ void km_labels_out(const int* __restrict__ labels32, int64_t* __restr
 
 // ---- workspace carve --------------------------------------------------------------------------
 struct KmWs {
-    KmState* st; float* Ca; float* Cb; float* partial; double* seg; float* dpart; int* labels32; int* order; int* start;
+    KmState* st; float* Ca; float* Cb; double* gpart; double* seg; double* dgpart; int* labels32; int* order; int* start;
     float* W; int* empty_rank; size_t bytes;
 };
 KmWs carve(void* base, int T, int64_t D, int K) {
-    const int64_t nch = (D + CH - 1) / CH;
+    const int64_t ng = (D + GW - 1) / GW;
     const size_t I = (size_t)T * K;
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
@@ -797,9 +807,9 @@ KmWs carve(void* base, int T, int64_t D, int K) {
     w.st = (KmState*)take(sizeof(KmState));
     w.Ca = (float*)take(sizeof(float) * (size_t)K * D);
     w.Cb = (float*)take(sizeof(float) * (size_t)K * D);
-    w.partial = (float*)take(sizeof(float) * (size_t)nch * I);
+    w.gpart = (double*)take(sizeof(double) * (size_t)ng * I);
     w.seg = (double*)take(sizeof(double) * NSEG * I);
-    w.dpart = (float*)take(sizeof(float) * (size_t)nch * K);
+    w.dgpart = (double*)take(sizeof(double) * (size_t)ng * K);
     w.labels32 = (int*)take(sizeof(int) * T);
     w.order = (int*)take(sizeof(int) * T);
     w.start = (int*)take(sizeof(int) * (K + 1));
@@ -812,8 +822,8 @@ KmWs carve(void* base, int T, int64_t D, int K) {
 template <typename Tag, int KB>
 void launch_assign_kb(bool vec, const void* X, const KmWs& w, int T, int64_t D, int K, int k0, int64_t nch, hipStream_t s) {
     const dim3 grid((unsigned)((nch + WPB - 1) / WPB)), block(WPB * 64);
-    if (vec) hipLaunchKernelGGL((km_assign<Tag, KB, true>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.partial, T, D, K, k0, nch);
-    else hipLaunchKernelGGL((km_assign<Tag, KB, false>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.partial, T, D, K, k0, nch);
+    if (vec) hipLaunchKernelGGL((km_assign<Tag, KB, true>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.gpart, T, D, K, k0, nch);
+    else hipLaunchKernelGGL((km_assign<Tag, KB, false>), grid, block, 0, s, X, w.Ca, w.Cb, w.st, w.gpart, T, D, K, k0, nch);
 }
 template <typename Tag>
 void launch_assign(bool vec, const void* X, const KmWs& w, int T, int64_t D, int K, int64_t nch, hipStream_t s) {
@@ -827,13 +837,66 @@ void launch_assign(bool vec, const void* X, const KmWs& w, int T, int64_t D, int
         }
     }
 }
+template <typename Tag>
+void launch_update(bool vec, const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* fill_idx, int n_fill,
+                   int T, int64_t D, int K, int64_t nch, int empty_mode, hipStream_t s) {
+    const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
+    const size_t sh = sizeof(float) * (size_t)K * NSL;
+    if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, sh, s, X, Ca, Cb, w.st, wts, w.order, w.start, w.W, w.empty_rank,
+                                fill_idx, n_fill, w.dgpart, T, D, K, nch, empty_mode);
+    else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, sh, s, X, Ca, Cb, w.st, wts, w.order, w.start, w.W, w.empty_rank,
+                            fill_idx, n_fill, w.dgpart, T, D, K, nch, empty_mode);
+}
+
+// ---- the one-read pass: which shapes take it, and its launch ----------------------------------
+// SC_KM_FUSED=0 forces the two-pass kernels everywhere (same bits: tests/test_gpu_kmeans_fused.py compares the two paths).
+bool km2_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SC_KM_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+// rows-per-wave bucket of T: the slab holds RGW * 64 rows
+int km2_rgw(int T) { return T <= 64 ? 1 : T <= 128 ? 2 : T <= 256 ? 4 : T <= 448 ? 7 : 0; }
+template <typename Tag>
+bool km2_eligible(const void* X, int T, int64_t D, int K) {
+    if (!std::is_same<Tag, ScF16>::value || !km2_enabled()) return false;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || D % SW != 0 || !(K == 5 || K == 8)) return false;
+    const int rgw = km2_rgw(T);
+    if (rgw == 0) return false;
+    return (uint64_t)rgw * 64ull * (uint64_t)D * 2ull < (1ull << 32);           // the DMA's 32-bit row offsets (padded rows included)
+}
+template <int K, int RGW, int MODE>
+void km2_launch_inst(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D,
+                     hipStream_t s) {
+    constexpr size_t lds = km2_lds_bytes(K, RGW);
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)km2_pass<K, RGW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    const int64_t ng = (D + GW - 1) / GW;
+    hipLaunchKernelGGL((km2_pass<K, RGW, MODE>), dim3((unsigned)ng), dim3(KM2_NW * 64), lds, s, (const _Float16*)X, Ca, Cb, w.st, wts,
+                       w.order, w.start, w.W, w.empty_rank, reseed_idx, n_reseed, w.dgpart, w.gpart, T, D);
+}
+template <int K, int MODE>
+void km2_launch_k(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D, hipStream_t s) {
+    switch (km2_rgw(T)) {
+        case 1: km2_launch_inst<K, 1, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
+        case 2: km2_launch_inst<K, 2, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
+        case 4: km2_launch_inst<K, 4, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
+        default: km2_launch_inst<K, 7, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
+    }
+}
+template <int MODE>
+void km2_launch(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D, int K,
+                hipStream_t s) {
+    if (K == 5) km2_launch_k<5, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s);
+    else km2_launch_k<8, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s);
+}
 
 template <typename Tag>
 int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int32_t* init_idx, const int32_t* reseed_idx,
              int n_reseed, int max_iter, float tol, float* C, int64_t* labels, float* wsum, int32_t* info, void* ws,
              hipStream_t s) {
     const KmWs w = carve(ws, T, D, K);
-    const int64_t nch = (D + CH - 1) / CH;
+    const int64_t nch = (D + CH - 1) / CH, ng = (D + GW - 1) / GW;
     const size_t I = (size_t)T * K;
     const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     {
@@ -841,41 +904,20 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
         if (vec) hipLaunchKernelGGL((km_init<Tag, true>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
         else hipLaunchKernelGGL((km_init<Tag, false>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
     }
-    const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
     const dim3 rgrid((unsigned)((I + 255) / 256), NSEG);
-    // one-pass iterations (km_fused: update(i) + assign(i + 1) from a register-resident slab): fp16 rows, whole 512-column chunks, K = 5 or 8,
-    // T <= 400.  OPT-IN (SC_KM_FUSED=1): bit-identical to the two-kernel path (tests/test_gpu_kmeans_fused.py) and it does read X once per
-    // iteration, but it is SLOWER on MI355X - 1.47 ms per Lloyd iteration against 0.66 at T = 400, K = 5 (0.26 against 0.20 at T = 64, K = 8;
-    // profiles/r05_run_j_kmeans_fused.md): holding the 400 KiB slab takes one wave per SIMD with all 512 registers, and with nothing to
-    // switch to every dependent step of a row's distance tree (packed fma chain, three lane swaps, four LDS-crossbar shuffles) is paid at
-    // full latency - ~2000 cycles per row and wave, 6x the HBM time of the row.  km_assign hides exactly that with 8+ waves per SIMD.
-    static int fused_on = -1, n_cu = 0;
-    if (fused_on < 0) { const char* e = getenv("SC_KM_FUSED"); fused_on = (e && e[0] == '1') ? 1 : 0; }
-    const bool fused = fused_on && std::is_same<Tag, ScF16>::value && vec && D % CH == 0 && (K == 5 || K == 8) && T <= FNW * 100;
-    if (fused && n_cu == 0) { int dev = 0, n = 0; (void)hipGetDevice(&dev); n_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
-    auto launch_fused = [&](int do_assign) {
-        const unsigned g = (unsigned)(nch < sc_launch_cu_count(n_cu, s) ? nch : sc_launch_cu_count(n_cu, s));
-        const int rw = (T + FNW - 1) / FNW;
-#define SC_KF3(RWV, KV, AV) hipLaunchKernelGGL((km_fused<RWV, KV, AV>), dim3(g), dim3(FNW * 64), 0, s, (const _Float16*)X, w.Ca, w.Cb, w.st, wts, w.labels32, w.W, \
-                                               w.empty_rank, reseed_idx, n_reseed, w.dpart, w.partial, T, D, nch)
-#define SC_KF2(RWV, KV) do { if (do_assign) SC_KF3(RWV, KV, true); else SC_KF3(RWV, KV, false); } while (0)
-#define SC_KF(RWV) do { if (K == 5) SC_KF2(RWV, 5); else SC_KF2(RWV, 8); } while (0)
-        if (rw <= 16) SC_KF(16); else if (rw <= 32) SC_KF(32); else if (rw <= 64) SC_KF(64); else SC_KF(100);
-#undef SC_KF
-#undef SC_KF2
-#undef SC_KF3
-    };
+    // one-read iterations (km2_pass): the pass of iteration i computes C'(i) AND the distances of iteration i + 1 against it from one
+    // LDS-resident slab per slice: n + 1 reads of X for n Lloyd iterations instead of 2 n
+    const bool fused = km2_eligible<Tag>(X, T, D, K);
     for (int it = 0; it < max_iter; ++it) {
-        if (!fused || it == 0) launch_assign<Tag>(vec, X, w, T, D, K, nch, s);          // (fused: the partials of iteration it > 0 were written by km_fused(it - 1))
-        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 1);
+        if (!fused) launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+        else if (it == 0) km2_launch<2>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 1);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
         hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
-        if (fused) launch_fused(it + 1 < max_iter ? 1 : 0);
-        else if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
-                                         w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
-        else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, w.Ca, w.Cb, w.st, wts, w.order, w.start, w.W,
-                                w.empty_rank, reseed_idx, n_reseed, w.dpart, T, D, K, nch, 0);
-        hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dpart, w.st, K, nch, it, max_iter, tol, n_reseed);
+        if (!fused) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
+        else if (it + 1 < max_iter) km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        else km2_launch<1>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dgpart, w.st, K, ng, it, max_iter, tol, n_reseed);
     }
     hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
     SC_CHECK_LAUNCH("sc_kmeans_fit");
@@ -885,38 +927,35 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
 template <typename Tag>
 int assign_impl(const void* X, int T, int64_t D, int K, const float* C, int64_t* labels, double* dist2, void* ws, hipStream_t s) {
     KmWs w = carve(ws, T, D, K);
-    const int64_t nch = (D + CH - 1) / CH;
+    const int64_t nch = (D + CH - 1) / CH, ng = (D + GW - 1) / GW;
     const size_t I = (size_t)T * K;
     const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     hipLaunchKernelGGL(km_set_state, dim3(1), dim3(1), 0, s, w.st, 0);
     w.Ca = const_cast<float*>(C);   // read-only use: state.cur == 0 selects Ca
-    launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
-    hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.partial, w.st, w.seg, I, nch, 0);
+    if (km2_eligible<Tag>(X, T, D, K) && (reinterpret_cast<uintptr_t>(C) & 31) == 0) km2_launch<2>(X, w.Ca, w.Cb, w, nullptr, nullptr, 0, T, D, K, s);
+    else launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+    hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 0);
     hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, dist2, T, K, 0);
     hipLaunchKernelGGL(km_labels_out, dim3((T + 255) / 256), dim3(256), 0, s, w.labels32, labels, T);
     SC_CHECK_LAUNCH("sc_kmeans_assign");
     return SC_OK;
 }
 
-// one centroid update from given labels: C_new[k] = sum_{t: label t = k} w_t x_t / W_k (rows in ascending order, SC-KM1), an empty
+// one centroid update from given labels: C_new[k] = sum_{t: label t = k} w_t x_t / W_k (rows in ascending order), an empty
 // cluster takes row fill_idx[its rank among the empty clusters] (empty_mode 0) or the zero vector (empty_mode 1)
 template <typename Tag>
 int update_impl(const void* X, int T, int64_t D, int K, const float* wts, const int64_t* labels, const float* C_old, int empty_mode,
                 const int32_t* fill_idx, int n_fill, float* C_new, float* wsum, double* shift2, void* ws, hipStream_t s) {
     KmWs w = carve(ws, T, D, K);
-    const int64_t nch = (D + CH - 1) / CH;
+    const int64_t nch = (D + CH - 1) / CH, ng = (D + GW - 1) / GW;
     const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(C_old) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(C_new) & 15) == 0);
     hipLaunchKernelGGL(km_set_state, dim3(1), dim3(1), 0, s, w.st, 0);
     hipLaunchKernelGGL(km_labels_in, dim3((T + 255) / 256), dim3(256), 0, s, labels, w.labels32, T, K);
     hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 0);
-    const dim3 sgrid((unsigned)((nch + WPB - 1) / WPB)), sblock(WPB * 64);
     float* Ca = const_cast<float*>(C_old);        // state.cur == 0: Ca is read (old centroids), Cb written
-    if (vec) hipLaunchKernelGGL((km_update<Tag, true>), sgrid, sblock, 0, s, X, Ca, C_new, w.st, wts, w.order, w.start, w.W, w.empty_rank,
-                                fill_idx, n_fill, w.dpart, T, D, K, nch, empty_mode);
-    else hipLaunchKernelGGL((km_update<Tag, false>), sgrid, sblock, 0, s, X, Ca, C_new, w.st, wts, w.order, w.start, w.W, w.empty_rank,
-                            fill_idx, n_fill, w.dpart, T, D, K, nch, empty_mode);
-    hipLaunchKernelGGL(km_shift_out, dim3(1), dim3(256), 0, s, w.dpart, w.W, shift2, wsum, K, nch);
+    launch_update<Tag>(vec, X, Ca, C_new, w, wts, fill_idx, n_fill, T, D, K, nch, empty_mode, s);
+    hipLaunchKernelGGL(km_shift_out, dim3(1), dim3(256), 0, s, w.dgpart, w.W, shift2, wsum, K, ng);
     SC_CHECK_LAUNCH("sc_kmeans_update");
     return SC_OK;
 }

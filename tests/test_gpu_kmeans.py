@@ -31,8 +31,8 @@ def test_kmeans_matches_reference_golden(path):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("T,D,K", [(40, 512 * 3, 5), (64, 1024 + 8, 8), (37, 520, 3), (50, 100, 4), (300, 2048, 16), (70, 4096, 20)])
 def test_kmeans_bit_exact_vs_oracle(dtype, T, D, K):
-    """labels AND centroids bit-identical to the oracle (shared SC-KM1 reduction spec), incl. unaligned D (100)
-    and K > 16 (two centroid tiles)."""
+    """labels AND centroids bit-identical to the oracle (shared SC-KM2 reduction spec), incl. unaligned D (100)
+    and K > 16 (two centroid tiles).  (40, 1536, 5) and (64, 1032, 8): the lane-mapped kernels; fp16 + D % 64 == 0 + K in {5, 8} takes km2_pass.)"""
     g = torch.Generator().manual_seed(T * 1000 + D + K)
     centres = torch.randn(max(K - 1, 2), D, generator=g)
     X = (centres[torch.randint(0, centres.shape[0], (T,), generator=g)] + 0.3 * torch.randn(T, D, generator=g)).to(dtype)
@@ -45,6 +45,30 @@ def test_kmeans_bit_exact_vs_oracle(dtype, T, D, K):
     assert int(info[0]) == ref["iters"]
     assert np.array_equal(C.cpu().numpy(), ref["centroids"])                      # bit-exact, not just close
     assert np.array_equal(wsum.cpu().numpy(), ref["wsum"])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("T,D,K", [(23, 64 * 9, 8), (64, 2048 * 3, 8), (90, 2048 + 64 * 5, 5), (128, 4096, 5), (200, 64 * 70, 8),
+                                   (256, 2048 * 2 + 64, 5), (333, 64 * 41, 5), (400, 2048 * 5, 5), (448, 64 * 33, 8)])
+def test_one_read_pass_bit_exact_vs_oracle(T, D, K, weighted):
+    """km2_pass (fp16, D % 64 == 0, K in {5, 8}, T <= 448: all four (row blocks, Q) instantiations, short last groups, weights, a forced
+    empty cluster) against the oracle: labels, centroids, weights and exit iteration bit-identical."""
+    g = torch.Generator().manual_seed(T * 7 + D + K)
+    centres = torch.randn(K + 1, D, generator=g)
+    X = (centres[torch.randint(0, K + 1, (T,), generator=g)] + 0.5 * torch.randn(T, D, generator=g)).half()
+    init = torch.randperm(T, generator=g)[:K].to(torch.int32)
+    if T % 2 == 0:
+        X[init[1]] = X[init[0]]                        # two identical initial rows: cluster 1 is empty after the first assign -> reseed path
+    reseed = torch.randint(0, T, (10 * K,), generator=g).to(torch.int32)
+    w = (0.5 + torch.rand(T, generator=g)) if weighted else None
+    ref = oracle.kmeans_fit(X.numpy(), K, init.numpy(), reseed.numpy(), weights=None if w is None else w.numpy(), max_iter=6)
+    C, labels, wsum, info = ops.kmeans_fit(X.cuda(), K, init, reseed, weights=None if w is None else w.cuda(), max_iter=6)
+    assert np.array_equal(labels.cpu().numpy(), ref["labels"])
+    assert int(info[0]) == ref["iters"]
+    assert np.array_equal(C.cpu().numpy(), ref["centroids"])
+    assert np.array_equal(wsum.cpu().numpy(), ref["wsum"])
+    lab2, d2 = ops.kmeans_assign(X.cuda(), C, return_dist2=True)
+    assert np.array_equal(d2.cpu().numpy(), oracle.kmeans_dist2(X.numpy(), ref["centroids"]))
 
 
 def test_kmeans_assign_dist2_bit_exact():

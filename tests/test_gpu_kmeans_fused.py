@@ -1,5 +1,6 @@
-"""kmeans.hip km_fused (round 5, opt-in SC_KM_FUSED=1): one pass over X per Lloyd iteration from a register-resident slab.  Must equal the
-two-kernel path bit for bit - labels, centroids, cluster weights, exit iteration - incl. the empty-cluster reseed and the weighted sums."""
+"""kmeans.hip km2_pass (round 6, the default for fp16 / K in {5, 8} / T <= 448; SC_KM_FUSED=0 switches it off): one pass over X per Lloyd
+iteration from an LDS-resident slab.  Must equal the two-pass lane-mapped kernels bit for bit - labels, centroids, cluster weights, exit
+iteration - incl. the empty-cluster reseed and the weighted sums (both implement SC-KM2; test_gpu_kmeans.py compares each with the oracle)."""
 import os
 import subprocess
 import sys
@@ -15,8 +16,8 @@ import sys, numpy as np, torch
 from streamchat_amd import ops
 out = {}
 g = torch.Generator(device="cuda").manual_seed(3)
-for name, (T, K, D, weighted, reseed) in dict(merge=(400, 5, 512 * 96, False, False), c1=(64, 8, 512 * 64, False, False), odd=(333, 5, 512 * 40, True, False),
-                                               small=(23, 8, 512 * 8, False, False), empty=(90, 5, 512 * 16, False, True)).items():
+for name, (T, K, D, weighted, reseed) in dict(merge=(400, 5, 512 * 96, False, False), c1=(64, 8, 512 * 64, False, False), odd=(333, 5, 512 * 40 + 64, True, False),
+                                               small=(23, 8, 512 * 8, False, False), empty=(90, 5, 512 * 16, False, True), mid=(200, 8, 64 * 50, True, False)).items():
     centres = torch.randn(6, D, device="cuda", generator=g)
     X = (centres[torch.randint(0, 6, (T,), device="cuda", generator=g)] + 0.6 * torch.randn(T, D, device="cuda", generator=g)).half()
     init = list(range(0, T, T // K))[:K]
@@ -39,7 +40,7 @@ def _run(tmp, fused):
 
 def test_fused_pass_equals_two_kernel_path_bitwise(tmp_path):
     a, b = _run(str(tmp_path), 0), _run(str(tmp_path), 1)
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 20
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 24
     for k in a.files:
         assert np.array_equal(a[k], b[k]), f"{k}: fused pass differs from the two-kernel path"
     assert int(a["empty_info"][2]) > 0, "the reseed case did not consume a reseed row"

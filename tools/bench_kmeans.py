@@ -31,9 +31,21 @@ for rep in range(a.reps):
     e1.record()
     torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1))
+def _time(fn, reps=5):
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return min(out)
+# breakdown (round 6): one assign pass alone; one Lloyd iteration (assign pass + update pass); n iterations = assign + (n - 1) fused + update
+C0 = X[init.to(dev)].float().contiguous()
+ms_assign = _time(lambda: ops.kmeans_assign(X, C0))
+ms_fit1 = _time(lambda: ops.kmeans_fit(X, a.K, init, None, max_iter=1, tol=-1.0))
 ms = min(res)
 per_iter = ms / a.iters
 algo = a.T * a.D * 2 + 2 * a.K * a.D * 4
 print(json.dumps(dict(T=a.T, K=a.K, D=a.D, iters=a.iters, ms_total=ms, ms_per_iter=per_iter,
                       algo_GBps_1x=algo / per_iter / 1e6, algo_GBps_2x=(algo + a.T * a.D * 2) / per_iter / 1e6,
-                      exit_iter=int(info[0]), all_ms=res)))
+                      exit_iter=int(info[0]), all_ms=res, ms_assign_only=ms_assign, ms_fit_1_iter=ms_fit1,
+                      ms_per_middle_iter=(ms - ms_fit1) / max(a.iters - 1, 1))))
