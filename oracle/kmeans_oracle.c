@@ -33,8 +33,14 @@
  *   - total   = the groups are cut into 32 contiguous segments of ceil(ngroups/32); each segment is
  *               summed in ascending group order in fp64, then the 32 segment sums in ascending order.
  *   - argmin on the fp64 totals (sqrt is monotone; first minimum wins).
- *   - update: per column, s = 0; for t in cluster (ascending): s = s + (w_t * x) in fp32 without
- *     fma contraction; C' = s / W (fp32 division).  W likewise sequential fp32.  (unchanged)
+ *   - update: the clusters are laid out one after the other in 8-row groups: cluster k has
+ *     ceil(n_k / 8) groups starting at group gs_k = sum_{k' < k} ceil(n_k' / 8).  The rows of a cluster
+ *     in ascending order have ranks j = 0, 1, ..; rank j belongs to chain
+ *     (wv, par) = ((gs_k + (j >> 3)) & 7, j & 1) - 16 chains: 8 waves x 2 half-waves each run one, and a
+ *     wave owns the same 8-row groups of the layout for every cluster (balanced whatever the sizes).
+ *     Per column: chain sum s[wv][par] = 0, then s = s + (w_t * x) over the chain's ranks ascending,
+ *     fp32 without fma contraction; u[wv] = s[wv][0] + s[wv][1]; S = u[0], S = S + u[wv] for wv = 1..7;
+ *     C' = S / W (fp32 division).  W = sequential fp32 sum of the cluster's weights, ascending.
  *   - shift: the same cell / slice / group / segment structure on (C_i - C')^2 per cluster, then
  *     sum_k sqrt(total_k) in fp64, compared with (double)tol.
  *
@@ -171,19 +177,29 @@ int sc_oracle_kmeans_fit(const void *X, int dtype, int T, int64_t D, int K, cons
             labels[t] = best;
             if (trace_labels) trace_labels[(size_t)i * T + t] = best;
         }
+        int gs = 0;                                   /* first 8-row group of the cluster in the sorted layout */
         for (int k = 0; k < K; ++k) {
             float W = 0.f;
-            for (int t = 0; t < T; ++t) if (labels[t] == k) W = W + (w ? w[t] : 1.0f);
+            int nk = 0;
+            for (int t = 0; t < T; ++t) if (labels[t] == k) { W = W + (w ? w[t] : 1.0f); ++nk; }
+            const int gsk = gs;
+            gs += (nk + 7) / 8;
             wsum[k] = W;
             float *cn = Cnew + (size_t)k * D;
             if (W > 0.f) {
 #pragma omp parallel for schedule(static)
                 for (int64_t j = 0; j < D; ++j) {
-                    float s = 0.f;
+                    float ch[8][2];
+                    for (int a = 0; a < 8; ++a) ch[a][0] = ch[a][1] = 0.f;
+                    int rank = 0;
                     for (int t = 0; t < T; ++t) if (labels[t] == k) {
                         float prod = (w ? w[t] : 1.0f) * ldx(X, dtype, (size_t)t * D + j);
-                        s = s + prod;
+                        float *c = &ch[(gsk + (rank >> 3)) & 7][rank & 1];
+                        *c = *c + prod;
+                        ++rank;
                     }
+                    float s = ch[0][0] + ch[0][1];
+                    for (int a = 1; a < 8; ++a) { float u = ch[a][0] + ch[a][1]; s = s + u; }
                     cn[j] = s / W;
                 }
             } else {

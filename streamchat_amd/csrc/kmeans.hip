@@ -367,38 +367,53 @@ __global__ __launch_bounds__(WPB * 64) void km_update(const void* __restrict__ X
         if (Wk > 0.f) {
             const int lo = start[k], hi = start[k + 1];
             constexpr int U = 8;
-            for (int i0 = lo; i0 < hi; i0 += U) {
-                float x[U][8];
-                float wt[U];
-                Raw8<Tag> raw[U];
+            // SC-KM2 update: rank j of the cluster's rows feeds chain ((gs_k + (j >> 3)) & 7, j & 1), gs_k = the cluster's first 8-row group in
+            // the cluster-sorted layout: chain group a takes the 8-rank batches b with (gs_k + b) & 7 == a, even ranks of a batch into s0, odd
+            // ones into s1; u_a = s0 + s1; the u_a are added in ascending a
+            int gsk = 0;
+            for (int kk = 0; kk < k; ++kk) gsk += (start[kk + 1] - start[kk] + 7) >> 3;
+            for (int a = 0; a < 8; ++a) {
+                float s0[8], s1[8];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u;
-                    if (i < hi) {
-                        const int t = order[i];
-                        wt[u] = w ? w[t] : 1.0f;
-                        if (VEC) {
-                            if (active) raw[u].load(X, (size_t)t * (size_t)D + (size_t)col);
-                            else raw[u].zero();
-                        } else load8_guard<Tag>(X, (size_t)t * (size_t)D, col, D, x[u]);
-                    } else {
-                        wt[u] = 0.f;
-                        raw[u].zero();
+                for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+                for (int i0 = lo + U * ((a - gsk) & 7); i0 < hi; i0 += 8 * U) {
+                    float x[U][8];
+                    float wt[U];
+                    Raw8<Tag> raw[U];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u;
+                        if (i < hi) {
+                            const int t = order[i];
+                            wt[u] = w ? w[t] : 1.0f;
+                            if (VEC) {
+                                if (active) raw[u].load(X, (size_t)t * (size_t)D + (size_t)col);
+                                else raw[u].zero();
+                            } else load8_guard<Tag>(X, (size_t)t * (size_t)D, col, D, x[u]);
+                        } else {
+                            wt[u] = 0.f;
+                            raw[u].zero();
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
+                        }
+                    }
+                    if (VEC) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) raw[u].unpack(x[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (i0 + u < hi) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {                     // mul, then add (1.0f * x == x exactly)
+                                if (u & 1) s1[e] = w ? s1[e] + wt[u] * x[u][e] : s1[e] + x[u][e];
+                                else s0[e] = w ? s0[e] + wt[u] * x[u][e] : s0[e] + x[u][e];
+                            }
+                        }
                     }
                 }
-                if (VEC) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) raw[u].unpack(x[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (i0 + u < hi) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) cn[e] = w ? cn[e] + wt[u] * x[u][e] : cn[e] + x[u][e];   // mul, then add (1.0f * x == x exactly)
-                    }
-                }
+                for (int e = 0; e < 8; ++e) { const float u = s0[e] + s1[e]; cn[e] = (a == 0) ? u : cn[e] + u; }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) cn[e] = cn[e] / Wk;
@@ -467,9 +482,19 @@ __device__ __forceinline__ float km2_dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
+#ifdef KM2_TRACE
+// diagnostic build (tools/trace_km2.py): shader cycles of wave 0 per phase, summed over all workgroups and slices
+__device__ unsigned long long km2_trace[8];
+#define KM2_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); tr[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define KM2_STAMP(i) do { } while (0)
+#endif
 constexpr int KM2_NW = 8;                                                     // waves per workgroup
 constexpr int KM2_ROWB = SW * 2;                                              // bytes per slab row
-__host__ __device__ constexpr size_t km2_lds_bytes(int K, int RGW) { return (size_t)RGW * 64 * KM2_ROWB + (size_t)K * SW * 4; }
+// LDS: slab | new centroid slice [K][64] | per-wave chain sums [8][K][64] | weight of every slab position
+__host__ __device__ constexpr size_t km2_lds_bytes(int K, int RGW) {
+    return (size_t)RGW * 64 * KM2_ROWB + (size_t)K * SW * 4 + (size_t)KM2_NW * K * SW * 4 + (size_t)RGW * 64 * 4;
+}
 // waves per SIMD the register allocation must leave room for: as many workgroups as the LDS admits on a CU (at most 32 waves), over 4 SIMDs
 __host__ __device__ constexpr int km2_min_waves_per_simd(int K, int RGW) {
     int wgs = (int)((160 * 1024) / km2_lds_bytes(K, RGW));
@@ -479,13 +504,23 @@ __host__ __device__ constexpr int km2_min_waves_per_simd(int K, int RGW) {
     return wps > 4 ? 4 : wps;                                                 // (128 registers: the K = 8 centroid cells alone take 64)
 }
 
-// K clusters; RGW = 8-row groups per wave (the slab holds RGW * 64 rows >= T); MODE 1 = update, 2 = assign, 3 = both.
-//   slab      [RGW * 64][64] fp16, row-major, one 128-byte line per row: a DMA instruction brings 8 rows (1 KiB, lane-linear)
-//   update    wave k < K: lane = column; row r of the cluster is one 2-byte LDS read at r * 128 + 2 lane (a whole line per instruction)
+// K clusters; RGW = 8-row groups per wave (the slab holds RGW * 64 rows); MODE 1 = update, 2 = assign, 3 = both.
+//   slab      [RGW * 64][64] fp16, one 128-byte line per row; a DMA instruction brings one 8-row group (1 KiB, lane-linear).  In the update
+//             modes the rows are gathered SORTED BY CLUSTER, every cluster padded to whole 8-row groups with rows that read as zeros
+//             (out-of-range DMA): an 8-row group belongs to one cluster.
+//   ownership wave wv owns the groups i = wv, wv + 8, .. of the slab for EVERYTHING - it brings them in, adds them into the cluster sums and
+//             measures their rows - so no wave ever waits for another wave's rows: the slab needs no barrier, and the DMA of the next slice's
+//             group i is issued the moment the wave has read group i for the last time (a per-wave software pipeline; the only workgroup
+//             barriers are the two around the exchange of the K x 64 new centroid values).
+//   update    lane = (row parity = lane / 32, column pair = lane % 32): one 4-byte LDS read per row pair; the two half-waves are the two
+//             chains of the wave (SC-KM2: chain = (group index & 7, rank & 1)).  The half-waves are added (lanes ^ 32), the 8 waves' sums go
+//             through LDS and 64 K threads add them in wave order, divide by W and write C' (LDS + global).
 //   assign    lane = (row r8 = lane / 8 of an 8-row group, cell = lane % 8): the group's 1 KiB is read lane-linear (16 bytes per lane), the K
 //             centroid cells of the lane's cell sit in 8 K registers for the whole slice; cell partial in the lane, slice tree = three DPP adds
 //             across the 8 cell lanes (quad_perm 1-0-3-2, 2-3-0-1, row_half_mirror: pairs (a, a^1), (a, a^2), then the two halves - the
 //             adjacent-pair tree); lane (r8, cell = k) keeps the fp64 group total of (row, k).
+template <int N> __device__ __forceinline__ void km2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int K, int RGW, int MODE>
 __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void km2_pass(
         const _Float16* __restrict__ X, float* Ca, float* Cb, const KmState* __restrict__ st, const float* __restrict__ w,
@@ -494,12 +529,12 @@ __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void k
     static_assert(SW == 64 && NCELL == 8 && K <= 8, "km2_pass is written for 64-column slices");
     constexpr bool UPD = (MODE & 1) != 0, ASG = (MODE & 2) != 0;
     constexpr int NW = KM2_NW, ROWS = RGW * 64;
-    constexpr int NCH = RGW;                                                  // 64-row chunks of a cluster's row list (a cluster has at most ROWS rows)
-    constexpr int UB = 8;                                                     // rows whose LDS reads are in flight together in the update
     if (st->done) return;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const slab = smem;
     float* const cnew = reinterpret_cast<float*>(smem + (size_t)ROWS * KM2_ROWB);
+    float* const wsum = cnew + K * SW;                                        // [NW][K][64]
+    float* const wpos = wsum + NW * K * SW;                                   // [ROWS]
     const float* Cold = st->cur ? Cb : Ca;
     float* Cnew = st->cur ? Ca : Cb;
     const int lane = threadIdx.x & 63;
@@ -512,38 +547,61 @@ __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void k
     const unsigned rowbytes = (unsigned)(D * 2);
     const int rbase = UPD ? st->reseed_pos : 0;
 
-    // update: wave k's list of the rows of cluster k (ascending) as LDS row offsets, lane-distributed, and their weights
-    unsigned prow[NCH];
-    float pwt[NCH];
-    int pcnt = 0;
+    // layout of the slab: cluster k's run starts at group gs[k] and has ng[k] groups (update modes); plain row order otherwise
+    int gs[K], ng[K], ngtot;
     if constexpr (UPD) {
-        if (wv < K) {
-            const int lo = start[wv], hi = start[wv + 1];
-            pcnt = hi - lo;
+        int acc = 0;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int i = lo + 64 * c + lane;
-                const int r = i < hi ? order[i] : 0;
-                prow[c] = (unsigned)r * KM2_ROWB;
-                pwt[c] = (w && i < hi) ? w[r] : 1.0f;
+        for (int k = 0; k < K; ++k) { gs[k] = acc; ng[k] = (start[k + 1] - start[k] + 7) >> 3; acc += ng[k]; }
+        ngtot = acc;
+    } else {
+        ngtot = (T + 7) >> 3;
+    }
+    // this wave's groups i = wv + 8 ii: the cluster of the group (wave-uniform) and, per lane, the row at position r8 of the group
+    // (-1: padding, reads zeros) - the row the lane's DMA brings and whose distances the lane owns
+    int drow[RGW], kg[RGW];
+#pragma unroll
+    for (int ii = 0; ii < RGW; ++ii) {
+        const int i = wv + ii * NW;
+        int t = -1, kk = -1;
+        if constexpr (UPD) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (i >= gs[k] && i < gs[k] + ng[k]) {
+                    kk = k;
+                    const int j = (i - gs[k]) * 8 + r8;
+                    if (j < start[k + 1] - start[k]) t = order[start[k] + j];
+                }
             }
+            if (cell == 0) wpos[i * 8 + r8] = (w && t >= 0) ? w[t] : 1.0f;
+        } else {
+            if (i * 8 + r8 < T) t = i * 8 + r8;
         }
+        drow[ii] = t;
+        kg[ii] = kk;
     }
     double acc64[RGW];
 #pragma unroll
     for (int n = 0; n < RGW; ++n) acc64[n] = 0.0;
     double dsh = 0.0;                                                         // thread (k, cell 0): shift total of cluster k over the group
     const int sk = threadIdx.x / NCELL, scell = threadIdx.x % NCELL;          // (cluster, cell) of the shift threads
-
+    float Wmine = 0.f;                                                        // thread (k, column) of the final sum: W_k (fetched once: a load inside
+    if constexpr (UPD) { if (threadIdx.x < K * SW) Wmine = W[threadIdx.x / SW]; }   //  the slice loop would wait for the DMA that is in flight around it)
+    auto dma_group = [&](int ii, int64_t col0) {                              // this wave's group ii of the slice at column col0 -> LDS
+        const int i = wv + ii * NW;
+        const unsigned voff = drow[ii] >= 0 ? (unsigned)drow[ii] * rowbytes + (unsigned)(cell << 4) : extent;
+        km2_dma16(X, extent, slab + i * 1024, voff, (unsigned)(col0 * 2));
+    };
+#ifdef KM2_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    if constexpr (UPD && K * SW > 0) __syncthreads();                         // wpos is read by other lanes of the same wave only, but keep the launch simple
+#pragma unroll
+    for (int ii = 0; ii < RGW; ++ii) dma_group(ii, gcol);                      // prologue: the first slice
 #pragma unroll 1
     for (int sidx = 0; sidx < nsl; ++sidx) {
         const int64_t col0 = gcol + (int64_t)sidx * SW;
-        // ---- A: the slab of this slice -> LDS (rows >= T read as zeros: out of the buffer's range) ----
-#pragma unroll
-        for (int ii = 0; ii < RGW; ++ii) {
-            const int i = wv + ii * NW;                                       // 8-row group
-            km2_dma16(X, extent, slab + i * 1024, (unsigned)(i * 8 + r8) * rowbytes + (unsigned)(cell << 4), (unsigned)(col0 * 2));
-        }
+        const bool more = sidx + 1 < nsl;                                     // (uniform)
         float co[8];                                                          // the old centroid cell of the shift threads
         float cr[K][8];                                                       // assign: the K centroid cells of this lane's cell
         if (UPD && threadIdx.x < K * NCELL) sc_load8<ScF32>(Cold, (size_t)sk * (size_t)D + (size_t)col0 + (size_t)scell * 8, co);
@@ -551,50 +609,88 @@ __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void k
 #pragma unroll
             for (int k = 0; k < K; ++k) sc_load8<ScF32>(Cold, (size_t)k * (size_t)D + (size_t)col0 + (size_t)cell * 8, cr[k]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- B: update - wave k owns cluster k, lane = column; the cluster's rows in ascending order ----
+        KM2_STAMP(0);
+        km2_wait_vm<0>();                                                     // this wave's groups of the slice have landed (its own DMA: no barrier)
+        // (the centroid loads above are complete as well.  Say so to the compiler HERE: it counts vmcnt for its own loads only, and a wait it
+        //  places after the next slice's DMA has been issued would wait for that DMA too)
         if constexpr (UPD) {
-            if (wv < K) {
-                const int k = wv;
-                const float Wk = W[k];
-                const unsigned lanebits = (unsigned)lane * 2u;
-                float cn = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(co[e]));
+        }
+        if constexpr (ASG && !UPD) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(cr[k][e]));
+        }
+        KM2_STAMP(1);
+        // ---- B: update ----
+        if constexpr (UPD) {
+            const int par = lane >> 5, cp = lane & 31;
+            sc_f2 cs[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) cs[k] = sc_f2{0.f, 0.f};
+            static_for<0, RGW>([&](auto ic) {
+                constexpr int ii = decltype(ic)::value;
+                const int i = wv + ii * NW;
+                if (kg[ii] >= 0) {                                            // (wave-uniform)
+                    const char* base = slab + i * 1024 + par * KM2_ROWB + cp * 4;
+                    sc_f2 x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const sc_h2 v = *reinterpret_cast<const sc_h2*>(base + q * 2 * KM2_ROWB);
+                        x[q] = sc_f2{(float)v[0], (float)v[1]};
+                    }
+                    if (w) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const float wt = wpos[i * 8 + 2 * q + par]; x[q] = sc_f2{wt * x[q].x, wt * x[q].y}; }   // mul, then add
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (kg[ii] == k) {                                    // (wave-uniform: a scalar branch)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cs[k] = cs[k] + x[q];
+                        }
+                    }
+                }
+            });
+#pragma unroll
+            for (int k = 0; k < K; ++k) {                                     // u = chain(par 0) + chain(par 1)
+                cs[k].x = cs[k].x + __shfl_xor(cs[k].x, 32, 64);
+                cs[k].y = cs[k].y + __shfl_xor(cs[k].y, 32, 64);
+                if (par == 0) *reinterpret_cast<sc_f2*>(wsum + (wv * K + k) * SW + cp * 2) = cs[k];
+            }
+            if constexpr (!ASG) {                                             // update only: the slab has been read for the last time
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (more) {
+#pragma unroll
+                    for (int ii = 0; ii < RGW; ++ii) dma_group(ii, col0 + SW);
+                }
+            }
+            KM2_STAMP(2);
+            __syncthreads();
+            KM2_STAMP(3);
+            if (threadIdx.x < K * SW) {                                       // thread (k, column): the 8 waves' sums in wave order, / W
+                const int k = threadIdx.x / SW, col = threadIdx.x % SW;
+                const float Wk = Wmine;
+                float cn;
                 if (Wk > 0.f) {
-                    static_for<0, NCH>([&](auto cc) {
-                        constexpr int c = decltype(cc)::value;
-                        const int n = pcnt - 64 * c < 64 ? pcnt - 64 * c : 64;              // rows of the cluster in this chunk of its list (wave-uniform)
-                        int j = 0;
-                        for (; j + UB <= n; j += UB) {
-                            float xv[UB], wt[UB];
+                    float S = wsum[k * SW + col];
 #pragma unroll
-                            for (int u = 0; u < UB; ++u) {
-                                const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)prow[c], j + u);
-                                wt[u] = w ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt[c]), j + u)) : 1.0f;
-                                xv[u] = (float)*reinterpret_cast<const _Float16*>(slab + (so + lanebits));
-                            }
-#pragma unroll
-                            for (int u = 0; u < UB; ++u) cn = w ? cn + wt[u] * xv[u] : cn + xv[u];      // mul, then add (no contraction: -ffp-contract=off)
-                        }
-                        for (; j < n; ++j) {
-                            const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)prow[c], j);
-                            const float x = (float)*reinterpret_cast<const _Float16*>(slab + (so + lanebits));
-                            if (w) cn = cn + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt[c]), j)) * x;
-                            else cn = cn + x;
-                        }
-                    });
-                    cn = cn / Wk;
-                } else {                                                      // empty cluster: the reseed row (it is in the slab like every row)
+                    for (int a = 1; a < NW; ++a) S = S + wsum[(a * K + k) * SW + col];
+                    cn = S / Wk;
+                } else {                                                      // empty cluster: the reseed row, straight from memory
                     const int pos = rbase + empty_rank[k];
                     int r = 0;
                     if (reseed_idx && pos < n_reseed) r = reseed_idx[pos];
                     if (r < 0 || r >= T) r = 0;
-                    cn = (float)*reinterpret_cast<const _Float16*>(slab + ((unsigned)r * KM2_ROWB + lanebits));
+                    cn = (float)X[(size_t)r * (size_t)D + (size_t)col0 + (size_t)col];
                 }
-                cnew[k * SW + lane] = cn;
-                Cnew[(size_t)k * (size_t)D + (size_t)col0 + (size_t)lane] = cn;
+                cnew[k * SW + col] = cn;
+                Cnew[(size_t)k * (size_t)D + (size_t)col0 + (size_t)col] = cn;
             }
             __syncthreads();
+            KM2_STAMP(4);
             // ---- C: shift partial of the slice, one thread per (cluster, cell) ----
             if (wv < (K * NCELL + 63) / 64) {
                 float a0 = 0.f, a1 = 0.f;
@@ -620,13 +716,22 @@ __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void k
                 }
             }
         }
-        // ---- D: assign - lane (r8, cell) of 8-row group i = wv + ii NW ----
+        KM2_STAMP(5);
+        // ---- D: assign - lane (r8, cell) of this wave's groups; group ii of the NEXT slice is requested as soon as group ii has been read ----
         if constexpr (ASG) {
             static_for<0, RGW>([&](auto ic) {
                 constexpr int ii = decltype(ic)::value;
                 const int i = wv + ii * NW;
-                if (i * 8 < T) {                                              // (wave-uniform)
-                    const sc_h8 v = *reinterpret_cast<const sc_h8*>(slab + i * 1024 + lane * 16);
+                sc_h8 v;
+                const bool live = i < ngtot;                                  // (wave-uniform)
+                if (live) {
+                    v = *reinterpret_cast<const sc_h8*>(slab + i * 1024 + lane * 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");          // the 16 bytes are in registers: their LDS lines are free
+                }
+                __builtin_amdgcn_sched_barrier(0);                            // (the request stays HERE: sunk below the arithmetic it would start too late)
+                if (more) dma_group(ii, col0 + SW);
+                __builtin_amdgcn_sched_barrier(0);
+                if (live) {
                     float x[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
@@ -649,16 +754,18 @@ __global__ __launch_bounds__(KM2_NW * 64, km2_min_waves_per_simd(K, RGW)) void k
                     acc64[ii] += (double)mine;
                 }
             });
-            __syncthreads();                                                  // the slab is rewritten by the next slice's DMA
         }
+        KM2_STAMP(6);
     }
+#ifdef KM2_TRACE
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&km2_trace[i], tr[i]);
+#endif
     if constexpr (ASG) {
         const size_t I = (size_t)T * K;
 #pragma unroll
-        for (int ii = 0; ii < RGW; ++ii) {
-            const int row = (wv + ii * NW) * 8 + r8;
-            if (cell < K && row < T) gpart[(size_t)g * I + (size_t)row * K + cell] = acc64[ii];
-        }
+        for (int ii = 0; ii < RGW; ++ii)
+            if (cell < K && drow[ii] >= 0) gpart[(size_t)g * I + (size_t)drow[ii] * K + cell] = acc64[ii];
     }
     if constexpr (UPD) {
         if (threadIdx.x < K * NCELL && scell == 0) dgpart[(size_t)g * K + sk] = dsh;
@@ -855,13 +962,13 @@ bool km2_enabled() {
     if (on < 0) { const char* e = getenv("SC_KM_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
 }
-// rows-per-wave bucket of T: the slab holds RGW * 64 rows
-int km2_rgw(int T) { return T <= 64 ? 1 : T <= 128 ? 2 : T <= 256 ? 4 : T <= 448 ? 7 : 0; }
+// rows-per-wave bucket: the slab holds RGW * 64 rows and must take the T rows sorted by cluster with every cluster padded to whole 8-row groups
+int km2_rgw(int T, int K) { const int need = T + 7 * K; return need <= 64 ? 1 : need <= 128 ? 2 : need <= 256 ? 4 : need <= 448 ? 7 : 0; }
 template <typename Tag>
 bool km2_eligible(const void* X, int T, int64_t D, int K) {
     if (!std::is_same<Tag, ScF16>::value || !km2_enabled()) return false;
     if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || D % SW != 0 || !(K == 5 || K == 8)) return false;
-    const int rgw = km2_rgw(T);
+    const int rgw = km2_rgw(T, K);
     if (rgw == 0) return false;
     return (uint64_t)rgw * 64ull * (uint64_t)D * 2ull < (1ull << 32);           // the DMA's 32-bit row offsets (padded rows included)
 }
@@ -877,7 +984,7 @@ void km2_launch_inst(const void* X, float* Ca, float* Cb, const KmWs& w, const f
 }
 template <int K, int MODE>
 void km2_launch_k(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D, hipStream_t s) {
-    switch (km2_rgw(T)) {
+    switch (km2_rgw(T, K)) {
         case 1: km2_launch_inst<K, 1, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
         case 2: km2_launch_inst<K, 2, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
         case 4: km2_launch_inst<K, 4, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
@@ -961,6 +1068,14 @@ int update_impl(const void* X, int T, int64_t D, int K, const float* wts, const 
 }
 
 }  // namespace
+
+#ifdef KM2_TRACE
+extern "C" int sc_km2_trace_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(km2_trace), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(km2_trace), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 extern "C" size_t sc_kmeans_workspace_bytes(int T, int64_t D, int K) {
     if (T <= 0 || D <= 0 || K <= 0) return 0;
