@@ -8,21 +8,21 @@
 //   slice = KM_SW columns: adjacent-pair tree over its cells                      (8- / 16-lane butterfly, or one THREAD that owns the row)
 //   group = 2048 columns: slice partials added in ascending order in fp64
 //   total = 32 contiguous segments of groups in fp64, then the segment sums; argmin = first minimum of the fp64 totals
-//   update sums: per column, rows of the cluster in ascending order, sequential fp32, no contraction; shift: the distance structure on (C - C')^2
+//   update sums: per column 16 chains per cluster - rank j of the cluster's rows (ascending) feeds chain ((gs_k + (j >> 3)) & 7, j & 1), gs_k =
+//           the cluster's first 8-row group when the clusters are laid out one after the other in whole 8-row groups; chains sequential fp32,
+//           no contraction; u_a = chain(a, 0) + chain(a, 1), S = u_0 + u_1 + .. + u_7 in that order, C' = S / W; shift: the distance structure on (C - C')^2
 // SC-KM1 (rounds 1-5) had a 64-lane tree per (row, cluster, 512-column chunk); that tree is why the one-read pass of round 5 (km_fused) could
 // only hold its slab in the register file of ONE wave per SIMD and ran 1.6 - 2.2x slower than two passes.  Under SC-KM2 nothing above the
 // cell needs a cross-lane step when a thread owns a row, so the slab can live in LDS and the pass runs at normal occupancy.
 //
 // Two kernel families, same bits:
-//   km2_pass<K, NRB, Q, MODE>   (fp16 rows, D % KM_SW == 0, K in {5, 8}, T <= 448)   ONE read of X per Lloyd iteration.
-//               A workgroup owns a 2048-column group and walks its slices; the [T, KM_SW] fp16 slab of a slice is brought into LDS by
-//               LDS-DMA (buffer_load ... lds, swizzled on the source address) and used twice:
-//                 update   wave k = cluster k, lane = column: the cluster's rows in ascending order from LDS (one xor + ds_read + cvt + add
-//                          per row), C' = sum / W -> LDS + global; the shift partial by (k, cell) threads;
-//                 assign   (for the NEXT iteration, against C') lane = row: x from LDS as 16-byte reads, the centroid cell as SGPR operands
-//                          (s_load of the C' this workgroup just wrote: wave-uniform, so the packed fp32 ops take it straight from
-//                          SGPRs), the cell / slice tree in registers, fp64 group accumulators per thread.
-//               MODE 2 = assign only (iteration 0), 1 = update only (last iteration), 3 = both.
+//   km2_pass<K, RGW, MODE>   (fp16 rows, D % 64 == 0, K in {5, 8}, 128 < T + 7 K <= 448)   ONE read of X per Lloyd iteration.
+//               A workgroup owns a 2048-column group and walks its 32 slices; the [T, 64] fp16 slab of a slice is gathered into LDS by
+//               LDS-DMA (buffer_load ... lds) SORTED BY CLUSTER and used twice - the update of iteration i and, against the C' that
+//               comes out of it, the distances of iteration i + 1.  Every wave owns the same 8-row groups of the slab for the DMA, the
+//               update and the assign, so the slab needs no barrier and the next slice's rows are requested while this slice's are
+//               measured (details at the kernel).  MODE 2 = assign only (iteration 0 and sc_kmeans_assign), 3 = both; the last iteration's
+//               update-only pass and every shape outside the range above run on
 //   km_assign / km_update        (any dtype, any D, K, T)   two passes over X per iteration; lane = 8 columns, rows streamed through registers.
 // Both are followed per iteration by km_reduce (segments) -> km_argmin -> km_order (stable counting sort, W[k], empty ranks) and km_decide
 // (sum_k ||C_i - C'||_2 < tol ? -> device-side `done` flag, no host round trip).
@@ -962,8 +962,10 @@ bool km2_enabled() {
     if (on < 0) { const char* e = getenv("SC_KM_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
 }
-// rows-per-wave bucket: the slab holds RGW * 64 rows and must take the T rows sorted by cluster with every cluster padded to whole 8-row groups
-int km2_rgw(int T, int K) { const int need = T + 7 * K; return need <= 64 ? 1 : need <= 128 ? 2 : need <= 256 ? 4 : need <= 448 ? 7 : 0; }
+// rows-per-wave bucket: the slab holds RGW * 64 rows and must take the T rows sorted by cluster with every cluster padded to whole 8-row groups.
+// Below ~130 rows a slice is too little work per workgroup step (two barriers, one DMA round trip): the two-pass kernels are as fast at
+// T = 100 and 25 % faster at T = 64, K = 8 (profiles/r06_run_a_kmeans_one_read_pass.md) - those shapes stay on them.
+int km2_rgw(int T, int K) { const int need = T + 7 * K; return need <= 128 ? 0 : need <= 256 ? 4 : need <= 448 ? 7 : 0; }
 template <typename Tag>
 bool km2_eligible(const void* X, int T, int64_t D, int K) {
     if (!std::is_same<Tag, ScF16>::value || !km2_enabled()) return false;
@@ -985,8 +987,6 @@ void km2_launch_inst(const void* X, float* Ca, float* Cb, const KmWs& w, const f
 template <int K, int MODE>
 void km2_launch_k(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D, hipStream_t s) {
     switch (km2_rgw(T, K)) {
-        case 1: km2_launch_inst<K, 1, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
-        case 2: km2_launch_inst<K, 2, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
         case 4: km2_launch_inst<K, 4, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
         default: km2_launch_inst<K, 7, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
     }
@@ -1021,9 +1021,9 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
         hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 1);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
         hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
-        if (!fused) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
-        else if (it + 1 < max_iter) km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
-        else km2_launch<1>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        // (the last iteration has no next assign: its update alone is a load-latency-bound pass for km2_pass - 0.49 ms against 0.42 for km_update)
+        if (!fused || it + 1 == max_iter) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
+        else km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
         hipLaunchKernelGGL(km_decide, dim3(1), dim3(256), 0, s, w.dgpart, w.st, K, ng, it, max_iter, tol, n_reseed);
     }
     hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
