@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU-baseline slice (SURVEY 8(d): 64 = C1's encode)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check the job instead of running it: visible GPUs, chunk partition, free HBM per rank, one 1-element all-gather and one "
+                         "point-to-point round per peer; ONE JSON line, exit code 0 / 3")
     ap.add_argument("--session", type=int, default=4, metavar="SEGMENTS",
                     help="AFTER the headline measurement (C3, one GPU): a stream of SEGMENTS segments with a --decode-tokens answer each, serial vs "
                          "reader/updater || QA-decode overlapped on two CU partitions (streamchat_amd/session.py); reported as `session`; 0 = off")
@@ -555,6 +558,47 @@ def relaunch_one_rank_per_gpu(n):
     return subprocess.call(cmd, env=dict(os.environ, SC_BENCH_SELF_LAUNCHED="1"))
 
 
+def preflight(a, rank, world, local):
+    """`bench.py --gpus N --preflight`: everything a first N-GPU run can trip over, checked in seconds, one JSON line from rank 0 (every rank
+    exits non-zero on an error; a rank that never arrives fails the others after SC_DIST_TIMEOUT_S)."""
+    import json as _json
+    rec, err = dict(preflight="ok", n_gpus=world, rank=rank), None
+    try:
+        have = torch.cuda.device_count()
+        rec["visible_gpus"] = have
+        if have <= local:
+            raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} but only {have} GPU(s) visible")
+        dev = torch.device(f"cuda:{local}")
+        torch.cuda.set_device(dev)
+        config = a.config or ("C2" if a.no_llm else "C3")
+        n_total = {"C1": 64, "C4": 4096}.get(config, (a.frames or FRAMES) * (a.rounds if config == "C5" else world))
+        parts = DD.partition_chunks(n_total if config != "C5" else n_total // a.rounds, 40, world)
+        rec["partition_frames_per_rank"] = [b - a_ for a_, b in parts]
+        free, total = torch.cuda.mem_get_info(dev)
+        # rank 0 holds the 7B model, its KV cache and the retrieved rows next to its shard's feature bank; the others bank + encoder only
+        need = (40 if rank == 0 else 12) * 2 ** 30 + (parts[rank][1] - parts[rank][0]) * 576 * 3584 * 2 * 2
+        rec["free_hbm_gb"], rec["need_hbm_gb"] = round(free / 2 ** 30, 1), round(need / 2 ** 30, 1)
+        if free < need:
+            raise RuntimeError(f"rank {rank}: {free / 2 ** 30:.1f} GB of HBM free, the step needs about {need / 2 ** 30:.1f} GB")
+        if world > 1:
+            backend = os.environ.get("SC_DIST_BACKEND", "nccl")
+            DD.init_process_group(backend, rank, world, dev)
+            rec["collectives"] = DD.warm_up(DD.DistContext(rank, world, dev, backend))
+            import torch.distributed as dist
+            frees = [None] * world
+            dist.all_gather_object(frees, rec["free_hbm_gb"])
+            rec["free_hbm_gb_per_rank"] = frees
+            dist.destroy_process_group()
+    except Exception as e:                                    # noqa: BLE001 - reported as ONE line, exit code 3
+        err = f"{type(e).__name__}: {e}"
+    if err is not None:
+        print(_json.dumps(dict(preflight="error", n_gpus=world, rank=rank, error=err)), flush=True)
+        return 3
+    if rank == 0:
+        print(_json.dumps(rec), flush=True)
+    return 0
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
@@ -564,15 +608,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("SC_ALL_RANKS_ON_GPU0") == "1":      # testing on a 1-GPU box: every rank of the job shares device 0
         local = 0
+    if a.preflight:
+        sys.exit(preflight(a, rank, world, local))
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         backend = os.environ.get("SC_DIST_BACKEND", "nccl")     # "gloo": host-staged collectives, for N > 1 runs on a 1-GPU box (tests)
-        dist.init_process_group(backend, **(dict(device_id=torch.device(f"cuda:{local}")) if backend == "nccl" else {}))
+        DD.init_process_group(backend, rank, world, torch.device(f"cuda:{local}"))       # explicit time-out (SC_DIST_TIMEOUT_S, 120 s) + device_id
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     ctx = DD.DistContext(rank, world, dev, os.environ.get("SC_DIST_BACKEND", "nccl") if world > 1 else "nccl")
+    dist_warm = DD.warm_up(ctx)                               # every communicator (collective + one point-to-point pair per peer) exists before step 1
     config = a.config or ("C2" if a.no_llm else "C3")
     full = config in ("C3", "C4", "C5") and not a.no_llm
     if config == "C1":
@@ -734,6 +779,9 @@ def main():
             "grow with the stream, so `value` scales with the frames per step while ms_per_step stays that of the serial tail + one "
             "rank's encode; read encode scaling from encode_frames_per_s against encode_frames_per_s_1gpu_same_job (rank 0 encoding its "
             "shard alone, other ranks idle at a barrier) or against the N = 1 record")
+    if world > 1:
+        out["dist_warm_up"] = dict(dist_warm, timeout_s=float(os.environ.get("SC_DIST_TIMEOUT_S", DD.DEFAULT_TIMEOUT_S)),
+                                   note="communicators (one all-gather, one point-to-point round per peer) created before the warm-up steps")
     if world > 1 and pipe.last.get("mem") is not None:         # row bytes that crossed ranks in the LAST step (merge-group pieces + selected rows), from the Refs
         tr = pipe.last["mem"].traffic
         out["collective"] = dict(kind="gather-to-root (batch_isend_irecv)", fetches_with_traffic=tr["fetches"], bytes_moved_last_step=tr["bytes_moved"],

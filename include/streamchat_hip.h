@@ -53,8 +53,12 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *      answer decode beside the MFMA-bound encode / prefill of the next segment); sc_attention_f16 decode path: grid and chunk shares
  *      changed (results of a split-KV call differ in the last bit from version 4's, every caller sees one consistent kernel)
  *   6  round 5: + sc_rope_qkv_rows_f16 (the batched decode step's rotary + KV-append in one launch)
+ *   7  round 6: - sc_set_cu_budget (the one piece of process-wide mutable state in the library: a CU-masked stream has carried its own CU
+ *      count since version 5, and that is the only way a persistent launch is sized now - "no global state besides the thread-local error
+ *      text" holds again); k-means: reduction spec SC-KM2 (labels of non-tied inputs unchanged; centroids / fp64 distances differ from
+ *      version 6's in the last bits), workspace layout changed (sc_kmeans_workspace_bytes says how much, as always)
  */
-#define SC_ABI_VERSION 6
+#define SC_ABI_VERSION 7
 
 int sc_abi_version(void);
 const char* sc_last_error(void);
@@ -62,13 +66,13 @@ const char* sc_last_error(void);
  * back to the default machine scheduler for attention.hip): performance numbers of different builds are not comparable - bench.py prints it */
 const char* sc_build_info(void);
 /* v5: CU-partitioned streams (hipExtStreamCreateWithCUMask).  A stream restricted to CUs [cu_first, cu_first + cu_count) of the device's CU
- * mask (consecutive mask bits go round-robin over the 8 XCDs: use multiples of 8).  sc_set_cu_budget(n) makes the library's persistent
- * launches (one workgroup per CU) size their grids for n CUs instead of the whole device (0 = whole device); it is process-wide: set it around
- * the launches that go to a masked stream.  The reference has no such notion; it runs reader / updater / QA as Python threads on one default
- * stream (reference previous_version/streaming_demo_llava_next_3.py:967-991). */
+ * mask.  Consecutive mask bits go round-robin over the 8 XCDs x 4 shader engines: use MULTIPLES OF 32 for both numbers (a partition that leaves
+ * the engines of an XCD unequal is paced by its smallest one: 112 / 144 CUs measured 25 - 35 % slower than 96 / 128).  The stream carries its CU
+ * count: the library's persistent launches (one workgroup per CU) size their grids for the stream they are launched on - per stream, no
+ * process-wide setting (v7 removed sc_set_cu_budget).  The reference has no such notion; it runs reader / updater / QA as Python threads on
+ * one default stream (reference previous_version/streaming_demo_llava_next_3.py:967-991). */
 int sc_stream_create_masked(int cu_first, int cu_count, int high_priority, sc_stream_t* out);
 int sc_stream_destroy(sc_stream_t stream);
-int sc_set_cu_budget(int n_cu);
 /* host out-params: number of CUs, 1 if the device is gfx950, total HBM bytes */
 int sc_device_info(int* cu_count, int* is_gfx950, size_t* hbm_bytes);
 
@@ -87,7 +91,7 @@ int sc_device_info(int* cu_count, int* is_gfx950, size_t* hbm_bytes);
  *   info       [4] int32 out: {exit_iter, status (0 ok, 1 = reseed stream exhausted),
  *              reseeds consumed, reserved}
  * Lloyd iterations run entirely on the device (no host round trip); iterations after
- * convergence are skipped by a device-side flag.  Reduction order: "SC-KM1" (DESIGN.md §4),
+ * convergence are skipped by a device-side flag.  Reduction order: "SC-KM2" (DESIGN.md section 2),
  * restated bit-for-bit by oracle/kmeans_oracle.c.
  */
 size_t sc_kmeans_workspace_bytes(int T, int64_t D, int K);
@@ -109,7 +113,7 @@ int sc_kmeans_assign(const void* X, int dtype, int T, int64_t D, int K, const fl
  *   labels  [T] int64 (device), values in [0, K)         w  [T] fp32 weights or NULL (all 1)
  *   C_old   [K, D] fp32 centroids the shift is measured against; C_new [K, D] fp32 out (must not alias C_old)
  *   empty_mode 0: the j-th empty cluster (ascending k) becomes row fill_idx[j] of X (row 0 if j >= n_fill); 1: zero vector
- *   wsum    [K] fp32 out or NULL: summed weights per cluster;  shift2 [K] fp64 out or NULL: ||C_old[k] - C_new[k]||^2 (SC-KM1 tree)
+ *   wsum    [K] fp32 out or NULL: summed weights per cluster;  shift2 [K] fp64 out or NULL: ||C_old[k] - C_new[k]||^2 (SC-KM2 order)
  * Same summation order as sc_kmeans_fit (rows of a cluster in ascending order, fp32, no contraction). */
 int sc_kmeans_update(const void* X, int dtype, int T, int64_t D, int K, const float* w, const int64_t* labels,
                      const float* C_old, int empty_mode, const int32_t* fill_idx, int n_fill, float* C_new,

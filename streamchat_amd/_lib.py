@@ -16,14 +16,13 @@ class StreamChatHipError(RuntimeError):
 
 
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
-ABI_VERSION = 6            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
+ABI_VERSION = 7            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),
     "sc_build_info": (c_char_p, []),
     "sc_stream_create_masked": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "sc_stream_destroy": (c_int, [c_void_p]),
-    "sc_set_cu_budget": (c_int, [c_int]),
     "sc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
     "sc_kmeans_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "sc_kmeans_fit": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,

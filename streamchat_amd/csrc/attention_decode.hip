@@ -3,6 +3,7 @@
 // attention.hip is built with hipcc's iterative-ILP machine scheduler (good for the MFMA-bound tile kernel: +3 % on the 49 k prefill),
 // which costs these HBM-bound kernels 0.6-2 % (profiles/r03_run49_51_attn_sched_strategy.md): this file takes the default scheduler.
 #include "sc_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -371,16 +372,16 @@ void sc_attn_decode_launch(const void* q, int ldq, const void* k, int ldk, const
     // SC_DEC_PD=1|2 pins the ring depth (A/B runs).  Default ONE stage per ring (64 KiB per workgroup): measured on the same box at a 49 k
     // context 326.2 tokens/s against 323.7 with two stages (64 splits; 325.6 / 315.5 at 128), and 11.53 against 11.47 ms on the 26-sequence
     // caption step - the run-ahead of a second stage buys nothing once the stream is all-DMA (profiles/r05_run_i_*)
-    static int pd_env = -1;
+    static std::atomic<int> pd_env{-1};
     if (pd_env < 0) { const char* e = getenv("SC_DEC_PD"); pd_env = e ? atoi(e) : 0; }
-    const int pd = (pd_env == 1 || pd_env == 2) ? pd_env : 1;
+    const int pd = (pd_env == 1 || pd_env == 2) ? pd_env.load() : 1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     auto go = [&](auto pdc) {
         constexpr int PD = decltype(pdc)::value;
         constexpr int LDS_RING = DEC_NW * 2 * PD * DCH * 128 * 2, LDS_MERGE = DEC_NW * (128 * 16 + 32) * 4;   // NW waves x (K ring + V ring) x PD stages of 8 KiB
         constexpr int LDS_DEC = LDS_RING > LDS_MERGE ? LDS_RING : LDS_MERGE;
-        static bool attr_done[16] = {};
+        static std::atomic<bool> attr_done[16];
         if (!attr_done[dev & 15]) { (void)hipFuncSetAttribute((const void*)k_attn_decode<128, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEC); attr_done[dev & 15] = true; }
         hipLaunchKernelGGL((k_attn_decode<128, PD>), dim3((unsigned)nsplit, (unsigned)Hq, (unsigned)B), dim3(64 * DEC_NW), LDS_DEC, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
                            (const _Float16*)v, ldv, Sq, Skv, Hq, Hkv, scale_log2, kv_len, part, nsplit, q_hs, q_bs, Hq / Hkv);

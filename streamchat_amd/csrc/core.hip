@@ -35,24 +35,20 @@ extern "C" int sc_device_info(int* cu_count, int* is_gfx950, size_t* hbm_bytes) 
 // launch needs: workgroups are dealt to the XCDs round-robin whatever the mask.
 // The persistent launches (one workgroup per CU) size their grids for the CUs of the STREAM they go to: a masked stream carries its CU count
 // (recorded when it is created), so two host threads driving two partitions never share a process-wide setting (round 5: the reader / updater
-// and the QA thread of streamchat_amd/session.py).  sc_set_cu_budget stays as the process-wide default for streams created elsewhere.
+// and the QA thread of streamchat_amd/session.py).  (ABI 7 removed the process-wide sc_set_cu_budget: the table below is the only source.)
+// One 64-bit word per slot - stream pointer's low 48 bits | CU count << 48 - so a reader never pairs a stream with another stream's count.
 #include <atomic>
-static std::atomic<int> g_cu_budget{0};
 static constexpr int SC_MAX_MASKED = 32;
-static std::atomic<void*> g_masked_stream[SC_MAX_MASKED];
-static std::atomic<int> g_masked_cus[SC_MAX_MASKED];
+static std::atomic<unsigned long long> g_masked[SC_MAX_MASKED];
+static inline unsigned long long sc_pack_masked(const void* s, int cus) { return ((unsigned long long)(uintptr_t)s & 0xFFFFFFFFFFFFull) | ((unsigned long long)cus << 48); }
 int sc_launch_cu_count(int device_cus, hipStream_t stream) {
-    int n = g_cu_budget.load(std::memory_order_relaxed);
+    int n = 0;
     if (stream)
-        for (int i = 0; i < SC_MAX_MASKED; ++i)
-            if (g_masked_stream[i].load(std::memory_order_acquire) == (void*)stream) { n = g_masked_cus[i].load(std::memory_order_relaxed); break; }
+        for (int i = 0; i < SC_MAX_MASKED; ++i) {
+            const unsigned long long v = g_masked[i].load(std::memory_order_acquire);
+            if (v && (v & 0xFFFFFFFFFFFFull) == ((unsigned long long)(uintptr_t)stream & 0xFFFFFFFFFFFFull)) { n = (int)(v >> 48); break; }
+        }
     return (n > 0 && n < device_cus) ? n : device_cus;
-}
-
-extern "C" int sc_set_cu_budget(int n_cu) {
-    SC_REQUIRE(n_cu >= 0, "sc_set_cu_budget: negative CU count");
-    g_cu_budget.store(n_cu, std::memory_order_relaxed);
-    return SC_OK;
 }
 
 extern "C" int sc_stream_create_masked(int cu_first, int cu_count, int high_priority, sc_stream_t* out) {
@@ -69,13 +65,12 @@ extern "C" int sc_stream_create_masked(int cu_first, int cu_count, int high_prio
     (void)high_priority;               // (hipExtStreamCreateWithCUMask takes no priority; the CU partition is what separates the two streams)
     e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((n + 31) / 32), mask);
     if (e != hipSuccess) return sc_fail(SC_ERR_LAUNCH, "sc_stream_create_masked: %s", hipGetErrorString(e));
-    for (int i = 0; i < SC_MAX_MASKED; ++i) {            // remember the partition's size for sc_launch_cu_count (a full table: the process-wide default applies)
-        void* expect = nullptr;
-        if (g_masked_stream[i].load(std::memory_order_relaxed) == nullptr) {
-            g_masked_cus[i].store(cu_count, std::memory_order_relaxed);
-            if (g_masked_stream[i].compare_exchange_strong(expect, (void*)s, std::memory_order_release)) break;
-        }
+    bool kept = false;
+    for (int i = 0; i < SC_MAX_MASKED && !kept; ++i) {   // remember the partition's size for sc_launch_cu_count: stream and count claimed in ONE exchange
+        unsigned long long expect = 0;
+        kept = g_masked[i].compare_exchange_strong(expect, sc_pack_masked(s, cu_count), std::memory_order_acq_rel);
     }
+    if (!kept) { (void)hipStreamDestroy(s); return sc_fail(SC_ERR_UNSUPPORTED, "sc_stream_create_masked: more than %d masked streams alive", SC_MAX_MASKED); }
     *out = (sc_stream_t)s;
     return SC_OK;
 }
@@ -83,8 +78,8 @@ extern "C" int sc_stream_create_masked(int cu_first, int cu_count, int high_prio
 extern "C" int sc_stream_destroy(sc_stream_t s) {
     if (!s) return SC_OK;
     for (int i = 0; i < SC_MAX_MASKED; ++i) {
-        void* expect = (void*)s;
-        if (g_masked_stream[i].compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel)) break;
+        unsigned long long v = g_masked[i].load(std::memory_order_acquire);
+        if (v && (v & 0xFFFFFFFFFFFFull) == ((unsigned long long)(uintptr_t)s & 0xFFFFFFFFFFFFull) && g_masked[i].compare_exchange_strong(v, 0ull, std::memory_order_acq_rel)) break;
     }
     const hipError_t e = hipStreamDestroy((hipStream_t)s);
     if (e != hipSuccess) return sc_fail(SC_ERR_LAUNCH, "sc_stream_destroy: %s", hipGetErrorString(e));

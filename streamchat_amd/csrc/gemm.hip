@@ -19,6 +19,7 @@
 // 4 consecutive output columns of one row: bias / activation / residual / fp16 pack happen in
 // registers and leave as 8-byte stores.
 #include "sc_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1545,25 +1546,26 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 15;
-    static int force = -1;                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
+    static std::atomic<int> force{-1};                       // SC_GEMM_KERNEL=128|256 pins the variant (A/B benchmarking)
     if (force < 0) { const char* e = getenv("SC_GEMM_KERNEL"); force = e ? atoi(e) : 0; }
     if (force == 0 && M <= 32 && K % 128 == 0 && a_grp == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0)) {      // few rows: stream W once
         const dim3 grid((unsigned)(N / 16)), block(256);
         // both operands through LDS rings (k_gemm_skinny_l): K in whole 512-element quarters-of-stages; SC_SKINNY_LDS=0 pins the register-operand kernels
-        static int lds_on = -1;
+        static std::atomic<int> lds_on{-1};
         if (lds_on < 0) { const char* e = getenv("SC_SKINNY_LDS"), *gnr = getenv("SC_SKINNY_GENERIC"); lds_on = ((e && e[0] == '0') || (gnr && gnr[0] == '1')) ? 0 : 1; }
         // (K >= 2048: a strip has at least PD stages per wave, so the epilogue buffer of strip s + 2 is requested after strip s has been stored)
         // FEW strips only (N / 16 below two per CU: o, down, q|k|v, kv of the batched decode, the text encoders' K = 4096 projections).  Measured
         // at M = 26, same box, us per launch LDS / register operands (profiles/r05_run_o_skinny_lds.md): q 7.9 / 11.8, kv 6.9 / 11.1, o 8.0 / 12.1,
         // q|k|v 11.5 / 20.5, down 38.8 / 50.6 - but gate/up 67.4 / 59.6 and lm_head 268 / 231: with many strips per workgroup the x-resident
         // register kernel (k_gemm_skinny_x) reads x once per WORKGROUP, this one once per strip (543 MB of x through LDS for 271 MB of weights)
-        static int n_cu_l[16] = {};
+        static std::atomic<int> n_cu_l[16];
         if (n_cu_l[dev] == 0) { int n = 0; n_cu_l[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
         if constexpr (EPI == SC_EPI_NONE || EPI == SC_EPI_SWIGLU) if (lds_on && N / 16 < 2 * n_cu_l[dev] && K % 512 == 0 && K >= 2048 && lda % 8 == 0 && (!R || ldr % 8 == 0) &&
                                                                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
             const int strips = N / 16, cus = sc_launch_cu_count(n_cu_l[dev], s), gx = strips < cus ? strips : cus;
-            static bool attr_done[16][8] = {};
+            static std::atomic<bool> attr_done[16][8];
 #define SC_LSL(F32, MGV, PDV, SLOT) do { constexpr int LDSB = 4 * PDV * (4096 + MGV * 4096) + 3 * MGV * 4 * 64 * 4 + 2 * 2048;                                   \
+                SC_REQUIRE(K / 512 >= PDV, "sc_gemm_f16: k_gemm_skinny_l needs K / 512 >= %d stages per strip (its epilogue tile is double-buffered by strip parity)", PDV); \
                 if (!attr_done[dev][SLOT]) { (void)hipFuncSetAttribute((const void*)k_gemm_skinny_l<EPI, F32, MGV, PDV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done[dev][SLOT] = true; } \
                 hipLaunchKernelGGL((k_gemm_skinny_l<EPI, F32, MGV, PDV>), dim3((unsigned)gx), block, LDSB, s, (const _Float16*)A, lda, (const _Float16*)W,        \
                                    (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K, strips / gx, strips % gx); } while (0)
@@ -1573,12 +1575,12 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
         }
-        static int unrolled = -1;                 // SC_SKINNY_GENERIC=1 pins the run-time-loop kernel (A/B runs, bit-identity test)
+        static std::atomic<int> unrolled{-1};                 // SC_SKINNY_GENERIC=1 pins the run-time-loop kernel (A/B runs, bit-identity test)
         if (unrolled < 0) { const char* e = getenv("SC_SKINNY_GENERIC"); unrolled = (e && e[0] == '1') ? 0 : 1; }
         if constexpr (EPI == SC_EPI_NONE || EPI == SC_EPI_SWIGLU) if (unrolled && (K == 3584 || K == 18944)) {
 #define SC_LSU(F32, MGV, KWV, BTV) hipLaunchKernelGGL((k_gemm_skinny_u<EPI, F32, MGV, KWV, BTV>), grid, block, 0, s, (const _Float16*)A, lda, (const _Float16*)W, \
                                                       (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N)
-            static int xres = -1;                     // SC_SKINNY_XREG=0: the x-from-L2 kernel for K = 3584 too (A/B runs)
+            static std::atomic<int> xres{-1};                     // SC_SKINNY_XREG=0: the x-from-L2 kernel for K = 3584 too (A/B runs)
             if (xres < 0) { const char* e = getenv("SC_SKINNY_XREG"); xres = (e && e[0] == '0') ? 0 : 1; }
             static int n_cu_x[16] = {};
             if (n_cu_x[dev] == 0) { int n = 0; n_cu_x[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
@@ -1586,10 +1588,10 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // lm_head); with one strip per workgroup (the 3584-row projections) loading x first only delays the weights: k_gemm_skinny_u
             if (K == 3584 && xres && N / 16 >= 2 * n_cu_x[dev]) {
                 const int strips = N / 16, gx = sc_launch_cu_count(n_cu_x[dev], s);
-                static int lx = -1;                   // SC_SKINNY_LX=0: weights as register operands (k_gemm_skinny_x) instead of the LDS ring (k_gemm_skinny_lx)
+                static std::atomic<int> lx{-1};                   // SC_SKINNY_LX=0: weights as register operands (k_gemm_skinny_x) instead of the LDS ring (k_gemm_skinny_lx)
                 if (lx < 0) { const char* e = getenv("SC_SKINNY_LX"); lx = (e && e[0] == '0') ? 0 : 1; }
                 if (lx && lda % 8 == 0 && (!R || ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
-                    static bool lx_attr[16][4] = {};
+                    static std::atomic<bool> lx_attr[16][4];
 #define SC_LLX(F32, MGV, SLOT) do { constexpr int LDSB = 4 * 8 * 4096 + 3 * MGV * 4 * 64 * 4 + 4 * 2048;                                                        \
                         if (!lx_attr[dev][SLOT]) { (void)hipFuncSetAttribute((const void*)k_gemm_skinny_lx<EPI, F32, MGV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); lx_attr[dev][SLOT] = true; } \
                         hipLaunchKernelGGL((k_gemm_skinny_lx<EPI, F32, MGV>), dim3((unsigned)gx), block, LDSB, s, (const _Float16*)A, lda, (const _Float16*)W,           \
@@ -1630,9 +1632,9 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
     const bool wide_ok = out_f32 || (ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);      // 16-byte epilogue stores
     if (big && wide_ok && N % BN2 == 0 && K % BK2 == 0) {
         // 256x256 tiles; the 128x256 / two-workgroups-per-CU variant is kept for A/B runs (SC_GEMM_KERNEL=2561)
-        static int gmw = -1;                      // raster group for wide N (SC_GEMM_GMW overrides; A/B in profiles/)
+        static std::atomic<int> gmw{-1};                      // raster group for wide N (SC_GEMM_GMW overrides; A/B in profiles/)
         if (gmw < 0) { const char* e = getenv("SC_GEMM_GMW"); gmw = e ? atoi(e) : 4; }
-        const int gm_sel = (N / BN2) > 16 ? gmw : SC_GEMM_GM;
+        const int gm_sel = (N / BN2) > 16 ? gmw.load() : SC_GEMM_GM;
         const bool half = force == 2561;        // measured: the 256x256 tile wins at every K once the store tail is widened (K-sweep in profiles)
         const int bm = half ? 128 : 256;
         const int tM = (M + bm - 1) / bm, tN = N / BN2;
@@ -1640,22 +1642,22 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         const size_t lds2 = half ? 3 * (128 * BK2 * 2 + HALF2) : SC_GEMM_NS * STAGE2;
         const void* fn = half ? (out_f32 ? (const void*)k_gemm256<EPI, true, 1> : (const void*)k_gemm256<EPI, false, 1>)
                               : (out_f32 ? (const void*)k_gemm256<EPI, true, 2> : (const void*)k_gemm256<EPI, false, 2>);
-        static bool attr_done[16][16] = {};
+        static std::atomic<bool> attr_done[16][16];
         const int ai = EPI * 4 + (out_f32 ? 2 : 0) + (half ? 1 : 0);
         if (!attr_done[dev][ai]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done[dev][ai] = true; }
         // persistent walk (one workgroup per CU) when a workgroup gets more than one tile; needs an even number of K-steps (the
         // fragment register sets ping-pong in pairs) and at least DIST + 1 of them.  SC_GEMM_PERSIST=0 switches it off (A/B runs).
-        static int persist = -1, n_cu_dev[16] = {};
+        static std::atomic<int> persist{-1}, n_cu_dev[16];
         if (persist < 0) { const char* e = getenv("SC_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
         if (n_cu_dev[dev] == 0) {
             int cur = 0, n = 0;
             if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
             if (n_cu_dev[dev] <= 0) n_cu_dev[dev] = 256;
         }
-        const int n_cu = sc_launch_cu_count(n_cu_dev[dev], s);          // (sc_set_cu_budget: a CU-masked stream gets a persistent grid of its own size)
+        const int n_cu = sc_launch_cu_count(n_cu_dev[dev], s);          // (a CU-masked stream gets a persistent grid of its own size)
         const int nt_all = tM * tN, nk2 = K / BK2;
         // (measured, profiles/r01_run99: +2..4 % at K = 1024, -1..3.5 % at K >= 3584 where the per-tile epilogue is a small share)
-        static int fat = -1;
+        static std::atomic<int> fat{-1};
         if (fat < 0) { const char* e = getenv("SC_GEMM_FAT"); fat = e ? atoi(e) : 1; }
         if (fat && !half && !out_f32 && a_grp == 0 && K % 128 == 0 && (size_t)lda * 512 < (1ull << 31) && lda % 8 == 0 &&
             (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&          // 16-byte DMA granules
@@ -1663,7 +1665,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
             // fetched under the epilogue of the current one
             const bool fp = persist && fat != 2 && nt_all > n_cu;
-            static bool fattr[16][8][2] = {};
+            static std::atomic<bool> fattr[16][8][2];
             if (!fattr[dev][EPI][fp]) {
                 (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
                 fattr[dev][EPI][fp] = true;
@@ -1681,7 +1683,7 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
         hipLaunchKernelGGL((k_gemm256<EPI, F32, WRV>), grid2, block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
                            (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all)
         if (pers) {
-            static bool pattr[16][8] = {};
+            static std::atomic<bool> pattr[16][8];
             if (!pattr[dev][EPI]) { (void)hipFuncSetAttribute((const void*)k_gemm256<EPI, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); pattr[dev][EPI] = true; }
             hipLaunchKernelGGL((k_gemm256<EPI, false, 2, true>), dim3((unsigned)n_cu), block2, lds2, s, (const _Float16*)A, lda, (const _Float16*)W,
                                (const _Float16*)bias, (const _Float16*)R, ldr, C, ldc, M, N, K, tN, a_grp, a_grp_stride, a_grp_off, gm_sel, nt_all);
@@ -1714,7 +1716,7 @@ int launch_headed(const void* A, int lda, const void* W, const void* bias, void*
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 15;
-    static int n_cu_dev[16] = {};
+    static std::atomic<int> n_cu_dev[16];
     if (n_cu_dev[dev] == 0) {
         int cur = 0, n = 0;
         if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) == hipSuccess) n_cu_dev[dev] = n;
@@ -1723,7 +1725,7 @@ int launch_headed(const void* A, int lda, const void* W, const void* bias, void*
     const int n_cu = sc_launch_cu_count(n_cu_dev[dev], s), tM = (M + BM2 - 1) / BM2, tN = N / BN2, nt_all = tM * tN;
     const bool fp = nt_all > n_cu;                                   // persistent walk once there are more tiles than CUs (as in launch_gemm)
     const int gm_sel = tN > 16 ? 4 : SC_GEMM_GM;
-    static bool attr[16][2] = {};
+    static std::atomic<bool> attr[16][2];
     if (!attr[dev][fp]) {
         (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr[dev][fp] = true;

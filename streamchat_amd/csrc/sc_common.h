@@ -28,7 +28,6 @@ static inline int sc_fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return sc_fail(SC_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-// CUs a persistent launch should size its grid for: the device's, or the budget set by sc_set_cu_budget (core.hip)
 int sc_launch_cu_count(int device_cus, hipStream_t stream);      // CUs a persistent launch on `stream` may count on (core.hip)
 
 static inline size_t sc_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

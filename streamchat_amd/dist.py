@@ -23,7 +23,21 @@ class DistContext:
         return self.rank == 0
 
 
-def init_from_env(device_type="cuda"):
+DEFAULT_TIMEOUT_S = 120        # rendezvous and every collective: a rank that never arrives raises on the others instead of hanging for RCCL's 10 minutes
+
+
+def init_process_group(backend, rank, world, device=None, timeout_s=None):
+    """`dist.init_process_group` with an explicit time-out (SC_DIST_TIMEOUT_S, default 120 s) and, on RCCL, the rank's device (`device_id`:
+    the communicator is created eagerly on that device instead of lazily inside the first collective)."""
+    import datetime
+    t = float(os.environ.get("SC_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S) if timeout_s is None else timeout_s)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = dict(device_id=device) if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=t), **kw)
+
+
+def init_from_env(device_type="cuda", timeout_s=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and initialises the process group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -35,11 +49,32 @@ def init_from_env(device_type="cuda"):
     else:
         device, backend = torch.device("cpu"), "gloo"
     if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        kw = dict(device_id=device) if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        init_process_group(backend, rank, world, device if backend == "nccl" else None, timeout_s)
     return DistContext(rank, world, device, backend)
+
+
+def warm_up(ctx):
+    """Create every communicator the sharded step uses BEFORE the first timed (or user-visible) step: one 1-element all-gather (the
+    collective communicator) and one 1-element `exchange` with every peer (RCCL builds point-to-point channels lazily per pair, inside the
+    first send / recv - a first 8-GPU step would otherwise pay, or hang in, eight of them).  Returns what was done, for the record."""
+    if ctx.world == 1 or not dist.is_initialized():
+        return dict(world=ctx.world, all_gather=False, p2p_peers=0)
+    dev = ctx.device if ctx.backend == "nccl" else torch.device("cpu")
+    one = torch.full((1,), float(ctx.rank), device=dev)
+    got = torch.empty(ctx.world, device=dev)
+    dist.all_gather_into_tensor(got, one)
+    if got.tolist() != [float(r) for r in range(ctx.world)]:
+        raise RuntimeError(f"dist.warm_up: the all-gather returned {got.tolist()} on rank {ctx.rank}")
+    peers = 0
+    for shift in range(1, ctx.world):              # round `shift`: send to rank + shift, receive from rank - shift (every pair once per direction)
+        dst, src = (ctx.rank + shift) % ctx.world, (ctx.rank - shift) % ctx.world
+        box = torch.empty(1, device=dev)
+        exchange(ctx, [(one, dst)], [(box, src)])
+        if float(box.item()) != float(src):
+            raise RuntimeError(f"dist.warm_up: rank {ctx.rank} received {box.item()} from rank {src}")
+        peers += 1
+    dist.barrier()
+    return dict(world=ctx.world, all_gather=True, p2p_peers=peers, backend=ctx.backend)
 
 
 def partition_chunks(n_frames, chunk_size, world):

@@ -196,13 +196,56 @@ class LocalMemoryRetrieval:
         if len(docs) == 0:
             return None, loaded_files
         vecs = self._embed_docs(docs)
-        store = dict(docs=[dict(page_content=d.page_content, metadata=d.metadata) for d in docs])
         if vs_path:
-            os.makedirs(vs_path, exist_ok=True)
-            json.dump(store, open(os.path.join(vs_path, "index.json"), "w", encoding="utf-8"), ensure_ascii=False)
-            np.save(os.path.join(vs_path, "index.npy"), vecs.detach().cpu().numpy())
+            self._persist(vs_path, docs, vecs)
         self._last = (docs, vecs, vs_path)
         return vs_path, loaded_files
+
+    # ---- on-disk index: append-only (round 6).  The reference re-opens the saved FAISS index and ADDS to it (`FAISS.load_local ...
+    # add_documents ... save_local`, local_doc_qa.py:242-251); rounds 1-5 here re-serialised every document and copied every vector to the
+    # host after every question.  Now `index.jsonl` (one document per line) and `index.npy` (a .npy whose header is padded to a fixed
+    # 128 bytes, so the row count can be rewritten in place) only receive the rows that are new since the last write: one D2H copy of the new
+    # vectors.  A document list that is not an extension of what is on disk (another user, an edited history) rewrites both files. ----
+    _NPY_HEADER = 128
+
+    @staticmethod
+    def _doc_line(d):
+        return json.dumps(dict(page_content=d.page_content, metadata=d.metadata), ensure_ascii=False)
+
+    def _write_npy_header(self, f, rows, dim):
+        head = ("{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d), }" % (rows, dim)).encode("latin1")
+        pad = self._NPY_HEADER - 10 - len(head) - 1
+        if pad < 0:
+            raise ValueError("index.npy: header does not fit its fixed size")
+        f.seek(0)
+        f.write(b"\x93NUMPY\x01\x00" + int(self._NPY_HEADER - 10).to_bytes(2, "little") + head + b" " * pad + b"\n")
+
+    def _persist(self, vs_path, docs, vecs):
+        os.makedirs(vs_path, exist_ok=True)
+        jl, npy = os.path.join(vs_path, "index.jsonl"), os.path.join(vs_path, "index.npy")
+        lines = [self._doc_line(d) for d in docs]
+        done = getattr(self, "_persisted", {}).get(vs_path)
+        if done is None and os.path.exists(jl) and os.path.exists(npy):               # a previous process wrote this index
+            done = open(jl, encoding="utf-8").read().splitlines()
+        dim = int(vecs.shape[1])
+        n_old = len(done) if done is not None else 0
+        extend = done is not None and n_old <= len(lines) and lines[:n_old] == done and os.path.getsize(npy) == self._NPY_HEADER + n_old * dim * 4
+        if not extend:
+            n_old = 0
+        new_rows = vecs[n_old:].detach().to("cpu", dtype=__import__("torch").float32).numpy() if len(lines) > n_old else None     # ONLY the new vectors leave the device
+        with open(jl, "a" if extend else "w", encoding="utf-8") as f:
+            for ln in lines[n_old:]:
+                f.write(ln + "\n")
+        with open(npy, "r+b" if extend else "w+b") as f:
+            self._write_npy_header(f, len(lines), dim)
+            if new_rows is not None:
+                f.seek(self._NPY_HEADER + n_old * dim * 4)
+                f.write(np.ascontiguousarray(new_rows, np.float32).tobytes())
+            f.truncate(self._NPY_HEADER + len(lines) * dim * 4)
+        if os.path.exists(os.path.join(vs_path, "index.json")):                       # the whole-file format of rounds 1-5
+            os.remove(os.path.join(vs_path, "index.json"))
+        self._persisted = dict(getattr(self, "_persisted", {}), **{vs_path: lines})
+        self.persist_stats = dict(rows_total=len(lines), rows_written=len(lines) - n_old, appended=bool(extend))
 
     def load_memory_index(self, vs_path, device=EMBEDDING_DEVICE):
         import torch
@@ -210,8 +253,11 @@ class LocalMemoryRetrieval:
         if last is not None and last[2] == vs_path:
             docs, vecs = last[0], last[1]
         else:
-            store = json.load(open(os.path.join(vs_path, "index.json"), encoding="utf-8"))
-            docs = [Document(d["page_content"], d["metadata"]) for d in store["docs"]]
+            if os.path.exists(os.path.join(vs_path, "index.jsonl")):
+                recs = [json.loads(ln) for ln in open(os.path.join(vs_path, "index.jsonl"), encoding="utf-8").read().splitlines() if ln]
+            else:
+                recs = json.load(open(os.path.join(vs_path, "index.json"), encoding="utf-8"))["docs"]
+            docs = [Document(d["page_content"], d["metadata"]) for d in recs]
             vecs = torch.from_numpy(np.load(os.path.join(vs_path, "index.npy"))).to(device)
         return FlatL2VectorStore(docs, vecs, self.embeddings.embed_query, chunk_size=self.chunk_size,
                                  topk_fn=getattr(self, "topk_fn", None))

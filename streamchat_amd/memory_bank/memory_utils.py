@@ -18,7 +18,10 @@ def enter_name(name, memory, local_memory_qa, data_args, update_memory_index=Tru
         memory_index_path = os.path.join(data_args.memory_basic_dir, f"memory_index/{name}_index")
         os.makedirs(os.path.dirname(memory_index_path), exist_ok=True)
         if (not os.path.exists(memory_index_path)) or update_memory_index:
-            if os.path.exists(memory_index_path):
+            # (the reference deletes the directory here and rebuilds the index from every document, :78-79; this retriever writes the index
+            #  append-only - it compares what is on disk with the documents and adds only what is new, or rewrites it when the history is not an
+            #  extension of it (local_doc_qa.LocalMemoryRetrieval._persist) - so the directory stays; a retriever without that takes the reference's path)
+            if os.path.exists(memory_index_path) and not hasattr(local_memory_qa, "_persist"):
                 shutil.rmtree(memory_index_path)
             memory_index_path, _ = local_memory_qa.init_memory_vector_store(filepath=memory_dir, vs_path=memory_index_path,
                                                                             user_name=name, cur_date=cur_date)

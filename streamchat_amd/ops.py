@@ -491,11 +491,6 @@ def masked_stream(cu_first: int, cu_count: int, device=None):
     return s
 
 
-def set_cu_budget(n_cu: int):
-    """persistent launches (one workgroup per CU) size their grids for n_cu CUs (0: the whole device): set around launches on a masked stream"""
-    check(_lib.load().sc_set_cu_budget(int(n_cu)), "sc_set_cu_budget")
-
-
 def attention_workspace_bytes(B: int, Hq: int, Sq: int, nsplit: int, Dh: int) -> int:
     return B * Hq * Sq * nsplit * (Dh + 2) * 4 if nsplit > 1 else 0
 

@@ -26,8 +26,8 @@ def test_binding_covers_header(hip_lib):
 
 
 def test_abi_version_and_error_text(hip_lib):
-    assert hip_lib.sc_abi_version() == 6
-    assert b"abi=6" in hip_lib.sc_build_info() and b"attention=" in hip_lib.sc_build_info()
+    assert hip_lib.sc_abi_version() == 7
+    assert b"abi=7" in hip_lib.sc_build_info() and b"attention=" in hip_lib.sc_build_info()
     # argument validation happens before any device work, so it is callable without a GPU
     rc = hip_lib.sc_kmeans_fit(None, 0, 1, 8, 1, None, None, None, 0, 1, 1e-4, None, None, None, None, None, 0, None)
     assert rc == -1
@@ -42,6 +42,13 @@ def test_abi_version_matches_header_and_changelog_names_every_symbol_added_since
     log = src[src.index("ABI changelog"):src.index("#define SC_ABI_VERSION")]
     for name in ("sc_kmeans_update", "sc_decode_qkv_f16", "sc_pick_token_f32", "sc_sample_token_f32", "sc_attention_variant"):
         assert name in log and name in declared_symbols()
+    # ABI 7: the process-wide CU budget is gone from the header, the library and the binding; the INTEGRATION.md stub pins the SAME literal
+    assert "sc_set_cu_budget" not in declared_symbols() and not hasattr(hip_lib, "sc_set_cu_budget")
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert int(re.search(r"^SC_ABI_VERSION\s*=\s*(\d+)", integ, re.M).group(1)) == ver
+    assert "sc_abi_version() == SC_ABI_VERSION" in integ
+    from streamchat_amd import _lib
+    assert _lib.ABI_VERSION == ver
 
 
 def test_headed_gemm_says_unsupported_before_any_device_work(hip_lib):

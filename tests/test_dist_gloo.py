@@ -74,3 +74,60 @@ def test_fetch_modes_world2_gloo():
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(timeout=60) for p in ps]
     assert [r[1] for r in res] == [True, True]
+
+
+# ---- round 6: explicit time-out + communicator warm-up ----
+def _warm_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ctx = D.init_from_env("cpu", timeout_s=60)
+    q.put((rank, D.warm_up(ctx)))
+    torch.distributed.destroy_process_group()
+
+
+def test_warm_up_creates_every_pair_at_world_4():
+    world, port = 4, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    ps = [mpc.Process(target=_warm_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert all(got[r] == dict(world=4, all_gather=True, p2p_peers=3, backend="gloo") for r in range(world))
+
+
+def _lonely_worker(rank, world, port, q):
+    import time
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    t0 = time.time()
+    try:
+        D.init_from_env("cpu", timeout_s=4)            # rank `world - 1` never starts
+        q.put((rank, "joined", time.time() - t0))
+    except Exception as e:                              # noqa: BLE001
+        q.put((rank, type(e).__name__, time.time() - t0))
+
+
+def test_a_rank_that_never_arrives_raises_on_the_others_within_the_timeout():
+    world, port = 3, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    ps = [mpc.Process(target=_lonely_worker, args=(r, world, port, q)) for r in range(world - 1)]      # the last rank is missing
+    [p.start() for p in ps]
+    got = [q.get(timeout=90) for _ in range(world - 1)]
+    [p.join(30) for p in ps]
+    for rank, what, secs in got:
+        assert what != "joined", f"rank {rank} believes a 3-rank group formed with 2 ranks"
+        assert secs < 60, f"rank {rank} waited {secs:.0f} s for a 4 s time-out"
+
+
+def test_bench_preflight_reports_one_json_error_line_without_a_gpu():
+    """`bench.py --preflight` on a box where the check fails (no GPU here): ONE JSON line, exit code 3 - what a launcher script can act on."""
+    import json, subprocess, sys
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the failing leg needs a box without a GPU; the passing legs are in test_gpu_sharded.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preflight"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["preflight"] == "error" and "GPU" in rec["error"]

@@ -86,3 +86,45 @@ def test_build_prompt_with_search_memory_only_related():
     p = U.build_prompt_with_search_memory_only_related("q?", "User", object(), fake, meta, "[|User|]", "[|AI|]", "AI")
     assert '"\nA\nB\n"' in p
     assert U.build_prompt_with_search_memory_only_related("q?", "User", None, fake, meta, "[|User|]", "[|AI|]", "AI") is None
+
+
+def test_dialogue_index_is_persisted_append_only(tmp_path):
+    """Round 6 (reference local_doc_qa.py:242-251 re-opens the saved index and adds to it): after every question only the
+    NEW documents and the NEW vectors are written - index.jsonl grows by lines, index.npy by rows behind a fixed-size header - and a fresh
+    process reads the same index back; a history that is not an extension of what is on disk rewrites the files."""
+    args = types.SimpleNamespace(memory_basic_dir=str(tmp_path), memory_file="memory_0.json", language="en")
+    lm = Q.LocalMemoryRetrieval()
+    lm.init_cfg("minilm-l6", top_k=1, language="en", embedder=FakeEmb())
+    lm.topk_fn = oracle_topk
+    memory = {}
+    _, _, memory, _, _ = MU.enter_name("User", memory, lm, args)
+    vs = os.path.join(str(tmp_path), "memory_index/User_index")
+    sizes, n_docs = [], []
+    for r, (q, a) in enumerate([("where is the cup", "on the table"), ("who came in", "a man in a red coat"), ("what did he take", "the umbrella")]):
+        memory = MU.save_local_memory(memory, [[q, a]], "User", args)
+        _, _, memory, _, idx = MU.enter_name("User", memory, lm, args)
+        st = lm.persist_stats
+        n_docs.append(st["rows_total"])
+        assert st["appended"] == (r > 0) and st["rows_written"] == n_docs[-1] - (n_docs[-2] if r else 0), st
+        sizes.append(os.path.getsize(os.path.join(vs, "index.npy")))
+        arr = np.load(os.path.join(vs, "index.npy"))
+        assert arr.shape[0] == st["rows_total"] and sizes[-1] == 128 + arr.size * 4
+        lines = open(os.path.join(vs, "index.jsonl"), encoding="utf-8").read().splitlines()
+        assert len(lines) == st["rows_total"]
+        assert np.array_equal(arr, np.stack([text_vec(json.loads(ln)["page_content"]) for ln in lines]))
+    assert n_docs == sorted(n_docs) and n_docs[-1] > n_docs[0]
+    # a fresh process: reads the index, and appends to what it finds on disk
+    lm2 = Q.LocalMemoryRetrieval(); lm2.init_cfg("minilm-l6", top_k=1, language="en", embedder=FakeEmb()); lm2.topk_fn = oracle_topk
+    store = lm2.load_memory_index(vs, device="cpu")
+    assert lm2.search_memory("umbrella", store)[0][0].count("the umbrella") == 1
+    memory = MU.save_local_memory(memory, [["is it raining", "yes"]], "User", args)
+    MU.enter_name("User", memory, lm2, args)
+    assert lm2.persist_stats["appended"] and lm2.persist_stats["rows_written"] == lm2.persist_stats["rows_total"] - n_docs[-1]
+    # an edited history is not an extension: both files are rewritten
+    fp = os.path.join(str(tmp_path), "memory_0.json")
+    mem = json.load(open(fp))
+    first_date = sorted(mem["User"]["history"])[0]
+    mem["User"]["history"][first_date][0]["response"] = "under the chair"
+    json.dump(mem, open(fp, "w"))
+    MU.enter_name("User", mem, lm2, args)
+    assert not lm2.persist_stats["appended"] and lm2.persist_stats["rows_written"] == lm2.persist_stats["rows_total"]
