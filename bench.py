@@ -37,6 +37,10 @@ from streamchat_amd.mm_utils import tokenizer_image_token   # noqa: E402
 
 FRAMES = 1024
 MICRO_BATCH = int(os.environ.get("SC_MICRO_BATCH", "512"))     # frames per ViT pass: 512 x 577 rows = 1154 whole 256-row GEMM tiles, 6.6 GB of activations
+# scenes of the synthetic stream last 37 frames: NOT the chunk size (40), so a merge group of 400 frames holds ~11 scenes cut at arbitrary places
+# and the merge k-means (K = 5) of the timed step is a real Lloyd run (rounds 1-5 cut the scenes at the chunk boundaries: every chunk was one
+# scene and the k-means converged after its second pass - VERDICT r05 "bench hygiene")
+SCENE_LEN = 37
 MEM = dict(chunk_size=40, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5)   # inference_streamchat_v0.3.sh:12-19
 GFLOP_PER_FRAME = 385.1            # patch 0.69 + 23 x 15.88 + projector 19.03
 MFMA_PEAK_TF = 2500.0              # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
@@ -138,7 +142,7 @@ def measure_session(pipe, n_frames, segments, tokens, decode_cus_list):
     whether the two runs retrieved the same frames and produced the same tokens."""
     from streamchat_amd import session as SS
     dev = pipe.device
-    segs = [torch.from_numpy(synthetic.frame_stream(n_frames, seed=1234, start=i * n_frames)).to(dev) for i in range(segments)]
+    segs = [torch.from_numpy(synthetic.frame_stream(n_frames, seed=1234, start=i * n_frames, scene_len=SCENE_LEN)).to(dev) for i in range(segments)]
     qs = [f"segment {i}: where did I leave the {synthetic.VOCAB[(7 * i) % len(synthetic.VOCAB)]} and what was on the kitchen table" for i in range(segments)]
 
     def run(overlap, dc):
@@ -153,19 +157,30 @@ def measure_session(pipe, n_frames, segments, tokens, decode_cus_list):
         dt = time.perf_counter() - t0
         s.close()
         keep = [{k: r[k] for k in ("short", "path_text", "retrieved_rows", "retrieved_crc", "context", "first_token", "tokens")} for r in rec]
+        co = SS.StreamingSession.co_running(rec)
         del s
         torch.cuda.empty_cache()
-        return dt, keep
-    t_serial, ref = run(False, 0)
+        return dt, keep, co
+    t_serial, ref, co_serial = run(False, 0)
     out = dict(what="C3 with its 512-token answer as a stream of segments: serial (one stream, whole chip) vs reader/updater || QA-decode on two CU partitions and two host threads",
                segments=segments, frames_per_segment=n_frames, answer_tokens=tokens, context=[r["context"] for r in ref],
                serial_s=round(t_serial, 3), serial_frames_per_s=round(segments * n_frames / t_serial, 2), overlapped=[])
     for dc in decode_cus_list:
-        t, rec = run(True, dc)
-        out["overlapped"].append(dict(decode_cus=dc, s=round(t, 3), frames_per_s=round(segments * n_frames / t, 2), speedup=round(t_serial / t, 3), identical_to_serial=rec == ref))
+        t, rec, co = run(True, dc)
+        out["overlapped"].append(dict(decode_cus=dc, s=round(t, 3), frames_per_s=round(segments * n_frames / t, 2), speedup=round(t_serial / t, 3), identical_to_serial=rec == ref,
+                                      gpu_timeline=co))
     best = max(out["overlapped"], key=lambda r: r["frames_per_s"])
     out["overlapped_frames_per_s"], out["best_decode_cus"], out["speedup"] = best["frames_per_s"], best["decode_cus"], best["speedup"]
     out["identical_to_serial"] = all(r["identical_to_serial"] for r in out["overlapped"])
+    out["co_running_fraction"] = (best.get("gpu_timeline") or {}).get("co_running_fraction")
+    if co_serial:                                                # what the pipeline can reach: fill + (segments - 1) co-running periods + drain
+        m, d = co_serial["mfma_busy_ms"] / segments, co_serial["decode_busy_ms"] / segments
+        out["serial_gpu_ms_per_segment"] = dict(mfma_side=round(m, 1), decode=round(d, 1))
+        if best.get("gpu_timeline"):
+            period = (best["s"] * 1e3 - m - d) / max(segments - 1, 1)
+            out["steady_state"] = dict(period_ms=round(period, 1), speedup_many_segments=round((m + d) / period, 3),
+                                       note="overlapped time = first segment's MFMA side alone + (segments - 1) co-running periods + last decode alone; a longer stream approaches "
+                                            "speedup_many_segments")
     return out
 
 
@@ -183,7 +198,7 @@ class Pipeline:
         self.parts = DD.partition_chunks(n_total, MEM["chunk_size"], self.ctx.world)
         a, b = self.parts[self.ctx.rank]
         self.range, self.n = (a, b), b - a
-        self.frames = torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=a)).to(device)        # resident in HBM
+        self.frames = torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=a, scene_len=SCENE_LEN)).to(device)        # resident in HBM
         self.feats = torch.empty((b - a, cfg.num_patches, 3584), dtype=torch.float16, device=device)
         self.device = device
         self.kmeans_k = kmeans_k
@@ -298,7 +313,7 @@ class Pipeline:
         self.round_parts = DD.partition_chunks(per_round, MEM["chunk_size"], self.ctx.world)
         a, b = self.round_parts[self.ctx.rank]
         self.per_round = per_round
-        self.round_frames = [torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=r * per_round + a)).to(self.device) for r in range(rounds)]
+        self.round_frames = [torch.from_numpy(synthetic.frame_stream(b - a, seed=seed, start=r * per_round + a, scene_len=SCENE_LEN)).to(self.device) for r in range(rounds)]
         self.round_feats = [torch.empty((b - a, self.cfg.num_patches, 3584), dtype=torch.float16, device=self.device) for _ in range(rounds)]
         self.questions = [f"round {r}: where did I leave the {synthetic.VOCAB[(7 * r) % len(synthetic.VOCAB)]} and what was next to the "
                           f"{synthetic.VOCAB[(11 * r + 3) % len(synthetic.VOCAB)]}" for r in range(rounds)]
@@ -721,12 +736,13 @@ def main():
     if kn:
         iters = sum(i[0] + 1 for i in km_infos) or kn           # assign(+update) passes actually run (device-side exit iteration + 1)
         gbs = kw / kn * iters / max(kms, 1e-9) / 1e6
-        stages["kmeans"] = dict(bound="hbm", kernel="km_assign + km_update", launches=kn, lloyd_passes=iters, avg_ms=round(kms / kn, 4),
+        stages["kmeans"] = dict(bound="hbm", kernel="km2_pass (one read of X per Lloyd iteration) + first assign / last update", launches=kn, lloyd_passes=iters, avg_ms=round(kms / kn, 4),
                                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                                frac_counting_both_reads_of_X=round(2 * gbs / HBM_PEAK_GBS, 4))
+                                reads_of_X_per_lloyd_iteration=round((iters / kn + 1) / (iters / kn), 3),      # n + 1 reads for n iterations (rounds 1-5: 2 n)
+                                frac_counting_every_read_of_X=round((iters / kn + 1) / (iters / kn) * gbs / HBM_PEAK_GBS, 4))
     if kn and world == 1 and pipe.feats.shape[0] >= 400:
-        # the same merge k-means (T = 400, K = 5, D = 2 064 384, the step's own features) forced through all 10 Lloyd iterations (tol < 0): the
-        # synthetic stream cuts its scenes at the chunk size and converges at once; a real stream does not (tests/test_gpu_composed_shipped.py)
+        # the same merge k-means (T = 400, K = 5, D = 2 064 384, the step's own features) forced through all 10 Lloyd iterations (tol < 0): a
+        # fixed amount of work whatever the stream does (the timed step's own run stops when it converges)
         Xk = pipe.feats[:400].reshape(400, -1)
         init10 = list(range(0, 400, 80))
         ops.kmeans_fit(Xk, 5, init10, None, max_iter=10, tol=-1.0); torch.cuda.synchronize()
@@ -734,9 +750,10 @@ def main():
         e0.record(); _, _, _, info10 = ops.kmeans_fit(Xk, 5, init10, None, max_iter=10, tol=-1.0); e1.record(); torch.cuda.synchronize()
         ms10 = e0.elapsed_time(e1)
         b1 = 400 * Xk.shape[1] * 2 + 2 * 5 * Xk.shape[1] * 4
-        stages["kmeans_10_passes"] = dict(bound="hbm", kernel="km_assign + km_update", lloyd_passes=int(info10[0]) + 1, ms_total=round(ms10, 3), ms_per_pass=round(ms10 / 10, 4),
+        stages["kmeans_10_passes"] = dict(bound="hbm", kernel="km2_pass x 9 + first assign + last km_update", lloyd_passes=int(info10[0]) + 1, ms_total=round(ms10, 3), ms_per_pass=round(ms10 / 10, 4),
                                           achieved=round(b1 / (ms10 / 10) / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b1 / (ms10 / 10) / 1e6 / HBM_PEAK_GBS, 4),
-                                          note="1x basis (one read of X per pass); the one-read-per-pass kernel (km_fused, SC_KM_FUSED=1) is bit-exact and slower: profiles/r05_run_j_kmeans_fused.md")
+                                          note="1x basis (T D 2 + 2 K D 4 bytes per Lloyd iteration); round 6: SC-KM2 + the one-read pass km2_pass (11 reads of X for 10 iterations instead of 20): profiles/r06_run_a_kmeans_one_read_pass.md; "
+                                               "SC_KM_FUSED=0 runs the two-pass kernels (same bits)")
     per = {k: dict(launches=v[0], ms_per_step=round(v[1] / a.steps, 3)) for k, v in sorted(prof.items())}
     enc_fps = n_total * a.steps / max(t_enc, 1e-9)
     names = dict(C1="C1: 64-frame stream, ViT-L encode + ONE weighted_kmeans_feature(k=8) over all frames (no LLM)",

@@ -72,10 +72,18 @@ def parse_args(argv=None):
     p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
     p.add_argument("--overlap", type=int, nargs="?", const=128, default=0, metavar="DECODE_CUS",
                    help="reader / updater of the NEXT segment on a second host thread and CU partition while the answer is decoded on DECODE_CUS CUs "
-                        "(multiples of 32; the reference's three-thread design, previous_version/streaming_demo_llava_next_3.py:967-991; SURVEY 8(f).3)")
+                        "(multiples of 32; the reference's three-thread design, previous_version/streaming_demo_llava_next_3.py:967-991; SURVEY 8(f).3).  "
+                        "Greedy outputs are identical to the serial run; SAMPLED outputs (temperature > 0) are not reproducible from a seed in this mode: "
+                        "the answer and the next segment's captions draw from the device's one default generator in whatever order the two threads reach it")
     p.add_argument("--memory_tree_dir", type=str, default=None,
                    help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if args.num_beams != 1:
+        # the reference forwards num_beams to HF generate (:254); this build decodes greedily or by sampling only.  Said HERE, before a model
+        # is loaded and a video is read, not by a NotImplementedError out of the first answer (the shipped script runs num_beams 1,
+        # inference_streamchat_v0.3.sh:20)
+        p.error(f"--num_beams {args.num_beams}: beam search is not implemented in streamchat_amd (greedy / sampling only); use --num_beams 1")
+    return args
 
 
 class SyntheticCapture:
@@ -228,6 +236,9 @@ def run_inference(args):
         all_annotations = json.load(open(args.annotations, "r"))
     inference_count = 0
     look = Lookahead(model, args.overlap, main_device) if args.overlap else None
+    if look is not None:
+        import copy
+        look.tokenizer = copy.deepcopy(tokenizer)           # a HF fast tokenizer is not re-entrant: the look-ahead thread encodes with a copy of its own
     for anno in all_annotations:
         os.makedirs(args.memory_basic_dir, exist_ok=True)
         args.memory_file = "memory_{}.json".format(inference_count)
@@ -261,12 +272,13 @@ def run_inference(args):
         long_memory_tree, short_memory_buffer = None, None
         segments = list(zip(question_list, frame_line[:-1], frame_line[1:]))
 
-        def read_and_update(star, end, tree, short, summarizer):
+        def read_and_update(star, end, tree, short, summarizer, tok=None):
+            tok = tokenizer if tok is None else tok
             feature_bank = S.video_reader_thread_with_embedding(cap, total_frames, frame_rate, None, model, star, end, main_device, args.sample_rate,
                                                                 chunk_size=args.chunk_size)
             if len(feature_bank) > 0:
                 tree, short = S.updating_memory_buffer(
-                    feature_bank, tree, summarizer, tokenizer, args.multi_modal_memory, short_window=args.short_window,
+                    feature_bank, tree, summarizer, tok, args.multi_modal_memory, short_window=args.short_window,
                     remember_window=args.remember_window, tau=args.tau, compress_rate=args.compress_rate, chunk_size=args.chunk_size,
                     num_clusters=args.num_clusters, interval=args.interval, batch_captions=args.batch_captions)
             return feature_bank, tree, short
@@ -282,7 +294,7 @@ def run_inference(args):
                 # the next segment's reader / updater start when this answer's prefill is done, and the answer's token loop runs on the decode
                 # partition for as long as they are busy (the last answer of a video has nothing beside it: whole chip)
                 nxt = segments[si + 1]
-                look.arm(lambda a=nxt[1], b=nxt[2], t=long_memory_tree, sh=short_memory_buffer: read_and_update(a, b, t, sh, look.captioner))
+                look.arm(lambda a=nxt[1], b=nxt[2], t=long_memory_tree, sh=short_memory_buffer: read_and_update(a, b, t, sh, look.captioner, look.tokenizer))
                 gen_kw = dict(on_prefill_done=look.fire, decode_stream=look.s_hbm)
                 from streamchat_amd import ops
                 ops.move_to_stream_when(lambda: look.decoding and not look.busy, torch.cuda.current_stream(torch.device(main_device)))

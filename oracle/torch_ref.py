@@ -13,22 +13,46 @@ import torch
 import torch.nn.functional as F
 
 
+# ---- fp16 storage points (round 6, tests/test_gpu_heavy_tail.py) ----
+# `with storage(torch.float16):` rounds every tensor HF's half-precision modules WRITE (every nn.Linear / LayerNorm / softmax / activation /
+# residual output of transformers' CLIP, Qwen2 eager paths) to that dtype and back: the arithmetic stays fp32 per op, the roundings are where
+# an fp16 HF model has them.  It answers "how far is HF's own fp16 execution from the fp32 truth on THIS input" - the yardstick for the HIP
+# path on heavy-tailed activations, where a bound relative to max|ref| says nothing about the ordinary channels.  Outside the context
+# `_st` is the identity and every function below is the plain fp32 restatement it always was.
+import contextlib
+
+_STORE = [None]
+
+
+def _st(x):
+    return x if _STORE[0] is None else x.to(_STORE[0]).float()
+
+
+@contextlib.contextmanager
+def storage(dtype):
+    _STORE[0] = dtype
+    try:
+        yield
+    finally:
+        _STORE[0] = None
+
+
 def _ln(x, w, b, eps):
-    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+    return _st(F.layer_norm(x, (x.shape[-1],), w, b, eps))
 
 
 def _mha(x, sd, pre, heads, mask=None, causal=False):
     B, S, D = x.shape
     dh = D // heads
-    q = F.linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
-    k = F.linear(x, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
-    v = F.linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]).view(B, S, heads, dh).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    q = _st(F.linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"])).view(B, S, heads, dh).transpose(1, 2)
+    k = _st(F.linear(x, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"])).view(B, S, heads, dh).transpose(1, 2)
+    v = _st(F.linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])).view(B, S, heads, dh).transpose(1, 2)
+    s = _st(_st(q @ k.transpose(-1, -2)) * dh ** -0.5)
     if mask is not None:
-        s = s + mask
-    a = torch.softmax(s, dim=-1) @ v
+        s = _st(s + mask)
+    a = _st(_st(torch.softmax(s, dim=-1)) @ v)
     a = a.transpose(1, 2).reshape(B, S, D)
-    return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+    return _st(F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"]))
 
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -51,27 +75,27 @@ def clip_vision_hidden(sd, pixel_values, *, heads, patch, layers_run, eps=1e-5, 
     layers of (LN1, MHA, +res, LN2, fc1, quick_gelu, fc2, +res)."""
     p = prefix
     w = sd[p + "embeddings.patch_embedding.weight"]
-    x = F.conv2d(pixel_values, w, stride=patch)                        # [N, D, gh, gw]
+    x = _st(F.conv2d(pixel_values, w, stride=patch))                   # [N, D, gh, gw]
     N, D = x.shape[0], x.shape[1]
     x = x.flatten(2).transpose(1, 2)                                   # [N, P, D]
     cls = sd[p + "embeddings.class_embedding"].expand(N, 1, D)
-    x = torch.cat([cls, x], dim=1) + sd[p + "embeddings.position_embedding.weight"][None]
+    x = _st(torch.cat([cls, x], dim=1) + sd[p + "embeddings.position_embedding.weight"][None])
     x = _ln(x, sd[p + "pre_layrnorm.weight"], sd[p + "pre_layrnorm.bias"], eps)
     for i in range(layers_run):
         lp = f"{p}encoder.layers.{i}."
         h = _ln(x, sd[lp + "layer_norm1.weight"], sd[lp + "layer_norm1.bias"], eps)
-        x = x + _mha(h, sd, lp + "self_attn.", heads)
+        x = _st(x + _mha(h, sd, lp + "self_attn.", heads))
         h = _ln(x, sd[lp + "layer_norm2.weight"], sd[lp + "layer_norm2.bias"], eps)
-        h = F.linear(h, sd[lp + "mlp.fc1.weight"], sd[lp + "mlp.fc1.bias"])
-        h = h * torch.sigmoid(1.702 * h)                               # quick_gelu
-        x = x + F.linear(h, sd[lp + "mlp.fc2.weight"], sd[lp + "mlp.fc2.bias"])
+        h = _st(F.linear(h, sd[lp + "mlp.fc1.weight"], sd[lp + "mlp.fc1.bias"]))
+        h = _st(h * _st(torch.sigmoid(_st(1.702 * h))))                # quick_gelu
+        x = _st(x + _st(F.linear(h, sd[lp + "mlp.fc2.weight"], sd[lp + "mlp.fc2.bias"])))
     return x
 
 
 def mm_projector(sd, x, prefix=""):
     """mlp2x_gelu (reference multimodal_projector/builder.py:41-48): Linear -> GELU(erf) -> Linear; keys 0.* / 2.*"""
-    h = F.gelu(F.linear(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"]))
-    return F.linear(h, sd[prefix + "2.weight"], sd[prefix + "2.bias"])
+    h = _st(F.gelu(_st(F.linear(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"]))))
+    return _st(F.linear(h, sd[prefix + "2.weight"], sd[prefix + "2.bias"]))
 
 
 def encode_images(sd_vit, sd_proj, pixel_values, *, heads, patch, num_layers, select_layer=-2):
@@ -192,7 +216,7 @@ def sentence_embedding(sd, input_ids, attention_mask, *, heads, layers):
 # ---------------------------------------------------------------------------------------------------------
 def _rms(x, w, eps):
     v = x.float().pow(2).mean(-1, keepdim=True)
-    return w * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
+    return _st(w * _st((x.float() * torch.rsqrt(v + eps)).to(x.dtype)))      # HF Qwen2RMSNorm: fp32 inside, cast to the input dtype, then the weight
 
 
 def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, eps=1e-6, last_only=False, head_chunk=None, row_chunk=None):
@@ -208,9 +232,11 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
     fr = torch.outer(pos, inv)
     cos, sin = torch.cat([fr, fr], -1).cos(), torch.cat([fr, fr], -1).sin()
 
+    cos, sin = _st(cos), _st(sin)                 # (HF hands cos / sin to apply_rotary_pos_emb in the activations' dtype)
+
     def rot(t):                                   # t [h, L, d]
         t1, t2 = t[..., : head_dim // 2], t[..., head_dim // 2:]
-        return t * cos + torch.cat([-t2, t1], -1) * sin
+        return _st(_st(t * cos) + _st(torch.cat([-t2, t1], -1) * sin))
     mask = None if row_chunk else torch.full((L, L), float("-inf"), device=x.device).triu(1)
     for i in range(layers):
         p = f"model.layers.{i}."
@@ -230,9 +256,9 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
             h = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
             x = x + F.linear(F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"]), sd[p + "mlp.down_proj.weight"])
             break
-        q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(L, heads, head_dim).transpose(0, 1)
-        k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
-        v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(L, kv_heads, head_dim).transpose(0, 1)
+        q = _st(F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"])).view(L, heads, head_dim).transpose(0, 1)
+        k = _st(F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])).view(L, kv_heads, head_dim).transpose(0, 1)
+        v = _st(F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])).view(L, kv_heads, head_dim).transpose(0, 1)
         q, k = rot(q), rot(k)
         k = k.repeat_interleave(heads // kv_heads, dim=0)
         v = v.repeat_interleave(heads // kv_heads, dim=0)
@@ -247,13 +273,13 @@ def qwen2_logits(sd, embeds, *, heads, kv_heads, layers, head_dim, theta=1e6, ep
             a = torch.cat([torch.softmax(q[j:j + head_chunk] @ k[j:j + head_chunk].transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v[j:j + head_chunk]
                            for j in range(0, heads, head_chunk)])
         else:
-            a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(head_dim) + mask, dim=-1) @ v
-        x = x + F.linear(a.transpose(0, 1).reshape(L, heads * head_dim), sd[p + "self_attn.o_proj.weight"])
+            a = _st(_st(torch.softmax(_st(_st(_st(q @ k.transpose(-1, -2)) / math.sqrt(head_dim)) + mask), dim=-1)) @ v)
+        x = _st(x + _st(F.linear(a.transpose(0, 1).reshape(L, heads * head_dim), sd[p + "self_attn.o_proj.weight"])))
         h = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
-        m = F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"])
-        x = x + F.linear(m, sd[p + "mlp.down_proj.weight"])
+        m = _st(_st(F.silu(_st(F.linear(h, sd[p + "mlp.gate_proj.weight"])))) * _st(F.linear(h, sd[p + "mlp.up_proj.weight"])))
+        x = _st(x + _st(F.linear(m, sd[p + "mlp.down_proj.weight"])))
     x = _rms(x[-1:] if last_only else x, sd["model.norm.weight"], eps)
-    out = F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"])
+    out = _st(F.linear(x, sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"]))
     return out[0] if last_only else out
 
 

@@ -16,7 +16,15 @@ enqueuing both jobs serialises them.
 
 Results do not depend on the mode: every kernel's arithmetic is independent of the CU count and of what runs beside it, each segment's
 RNG draws are seeded per segment, the memory tree is replaced (never mutated) by an update, and the answer being decoded owns its KV cache
-(`Qwen2Model.shared_view`, two caches used alternately).  `overlap=False` runs the same jobs in the same order on the current stream."""
+(`Qwen2Model.shared_view`, two caches used alternately).  `overlap=False` runs the same jobs in the same order on the current stream.
+
+Cross-stream memory (an invariant, not an accident): tensors allocated by a job on its stream (feature bank, tree rows, short buffer, prompt
+embeddings) are read later by the other side's stream, and `ops.move_to_stream_when` moves a job to another stream in mid-flight.  The caching
+allocator may hand a freed block back to its ORIGINAL stream's pool while the other stream still reads it.  Two things make that impossible
+here and both are required: (1) every job ends in a host synchronisation of its stream (`.item()` of the first token, the token list of the
+decode) before its results are handed over, and the hand-over carries an event the consumer waits on; (2) everything handed over stays
+referenced (`self.banks`, the records' `keep`) until the consumer has been enqueued AND has synchronised - and, belt and braces, the tensors
+that cross are marked with `record_stream` for the consuming stream."""
 import queue
 import random
 import threading
@@ -31,7 +39,10 @@ IMAGE_TOKEN_INDEX = -200
 
 
 class _Worker(threading.Thread):
-    """FIFO of callables on one host thread; the first exception stops the worker and is re-raised by `drain()`."""
+    """FIFO of jobs on one host thread.  A job is a callable, optionally with `job.on_skip` (a callable): after the first exception the
+    worker runs no further job, but it still runs every queued job's `on_skip` - the bookkeeping a job would have done in its `finally`
+    (free its KV-cache slot, count itself out) - so that the other side fails fast in `drain()` instead of waiting 600 s for a slot that is
+    never released.  `submit()` raises at once when the worker has already failed."""
 
     def __init__(self, name):
         super().__init__(name=name, daemon=True)
@@ -48,9 +59,18 @@ class _Worker(threading.Thread):
                     fn()
                 except BaseException as e:          # noqa: BLE001 - handed to the caller's thread
                     self.exc = e
+            else:
+                skip = getattr(fn, "on_skip", None)
+                if skip is not None:
+                    try:
+                        skip()
+                    except BaseException:           # noqa: BLE001 - the first error is the one reported
+                        pass
             self.q.task_done()
 
     def submit(self, fn):
+        if self.exc is not None:
+            raise RuntimeError(f"session: worker {self.name} has failed: {self.exc!r}") from self.exc
         self.q.put(fn)
 
     def drain(self):
@@ -107,9 +127,17 @@ class StreamingSession:
         for e in self.slot_free:
             e.set()
 
+    def _stamp(self):
+        """a timing event on the stream this host thread is launching on right now (GPU time line of the two sides: `results()` turns the
+        stamps into milliseconds since the first one - when each side's job started and ended ON THE GPU, whatever the host threads did)"""
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
     # ---- the two jobs of a segment ----
     def _ingest_and_prefill(self, i, frames, question, new_video=False):
         rec = self.records[i]
+        rec["_ev"] = {"m0": self._stamp()}
         if new_video:                                                                   # the reference starts every video with an empty memory (:845-860)
             self.tree, self.search_cache, self.banks = None, U.CaptionEmbeddingCache(), self.banks[-2:]     # (the last banks may still feed an answer in flight)
         feats = self.encoder.encode_frames_u8(frames)                                   # reader: [n, 576, D] fp16, a bank of its own per segment
@@ -146,14 +174,21 @@ class StreamingSession:
         rec["context"], rec["first_token"] = int(embeds.shape[1]), first
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
+        rec["_ev"]["m1"] = self._stamp()
+        if self.overlap:                                                                # the decode side reads this segment's cache and embeddings
+            for st in (self.s_hbm, self.s_hbm_full):
+                embeds.record_stream(st)
+                feats.record_stream(st)
         return slot, first, ev, embeds                                                  # (embeds kept alive until the decode has been enqueued)
 
     def _decode(self, i, slot, first, ev, keep):
         try:
             torch.cuda.current_stream(self.device).wait_event(ev)
+            self.records[i]["_ev"]["d0"] = self._stamp()
             g = self.graphs[slot]
             g.start(first)
             self.records[i]["tokens"] = [first] + g.run(self.max_new - 1)
+            self.records[i]["_ev"]["d1"] = self._stamp()
         finally:
             self.slot_free[slot].set()                                                  # (also on an error: the reader / updater must not wait for ever)
             del keep
@@ -202,10 +237,23 @@ class StreamingSession:
                             ops.move_to_stream_when(None, None)
                 finally:
                     count("hbm", -1)
+            def hbm_skip():                                        # the decode worker had already failed: free the slot, count out
+                self.slot_free[slot].set()
+                count("hbm", -1)
+            hbm_job.on_skip = hbm_skip
             count("hbm", +1)
-            self.w_hbm.submit(hbm_job)
+            try:
+                self.w_hbm.submit(hbm_job)
+            except BaseException:
+                hbm_skip()
+                raise
+        mfma_job.on_skip = lambda: count("mfma", -1)
         count("mfma", +1)
-        self.w_mfma.submit(mfma_job)
+        try:
+            self.w_mfma.submit(mfma_job)
+        except BaseException:
+            count("mfma", -1)
+            raise
         return i
 
     def results(self):
@@ -214,7 +262,27 @@ class StreamingSession:
             self.w_mfma.drain()                                                         # (every decode job has been handed over once this returns)
             self.w_hbm.drain()
         torch.cuda.synchronize(self.device)
+        evs = [r["_ev"] for r in self.records if "_ev" in r and len(r["_ev"]) == 4]
+        if evs:
+            t0 = evs[0]["m0"]
+            for r in self.records:
+                e = r.pop("_ev", None)
+                if e is not None and len(e) == 4:
+                    r["gpu_ms"] = dict(mfma=(round(t0.elapsed_time(e["m0"]), 1), round(t0.elapsed_time(e["m1"]), 1)),
+                                       decode=(round(t0.elapsed_time(e["d0"]), 1), round(t0.elapsed_time(e["d1"]), 1)))
         return self.records
+
+    @staticmethod
+    def co_running(records):
+        """from the records' GPU time lines: (window ms, ms during which a reader / updater / prefill job AND an answer decode were both
+        executing, the MFMA side's busy ms, the decode side's busy ms)"""
+        iv = [r["gpu_ms"] for r in records if "gpu_ms" in r]
+        if not iv:
+            return None
+        both = sum(max(0.0, min(a["mfma"][1], b["decode"][1]) - max(a["mfma"][0], b["decode"][0])) for a in iv for b in iv)
+        lo, hi = min(x["mfma"][0] for x in iv), max(x["decode"][1] for x in iv)
+        return dict(window_ms=round(hi - lo, 1), both_ms=round(both, 1), mfma_busy_ms=round(sum(x["mfma"][1] - x["mfma"][0] for x in iv), 1),
+                    decode_busy_ms=round(sum(x["decode"][1] - x["decode"][0] for x in iv), 1), co_running_fraction=round(both / max(hi - lo, 1e-9), 3))
 
     def close(self):
         if self.overlap:

@@ -13,7 +13,7 @@ algorithm step for step so that labels agree with it (fixture G3b, tests/golden/
 
 RNG: the reference seeds a generator ON x.device; the draws here come from a CPU generator with the same seed, i.e. they equal the
 reference's draws for a CPU input (a CUDA generator produces a different stream upstream as well).
-Arithmetic: distances / sums run in the SC-KM1 order of kmeans.hip (fp32 products, fp64 totals) instead of torch.cdist + matmul:
+Arithmetic: distances / sums run in the SC-KM2 order of kmeans.hip (fp32 products, fp64 totals) instead of torch.cdist + matmul:
 labels are identical away from exact ties, centres agree to fp32 rounding.
 Not supported (raises): other distances / p-norms, `normalize`, different k per instance (the k_mask path, :531-535)."""
 from typing import NamedTuple, Optional

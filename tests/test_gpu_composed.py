@@ -2,7 +2,7 @@
 PyTorch path on the same frame inputs"): the SAME 64 seeded uint8 frames go through
 
   HIP   fused preprocess -> ViT-L/14-336 (23 layers) -> mlp2x_gelu (fp16 storage, fp32 accumulate) -> weighted_kmeans_feature(K=8)
-  CPU   oracle/torch_ref: HF-arithmetic preprocess + ViT-L + projector in fp32 -> oracle.kmeans_fit (C, SC-KM1 order) on fp32 features
+  CPU   oracle/torch_ref: HF-arithmetic preprocess + ViT-L + projector in fp32 -> oracle.kmeans_fit (C, SC-KM2 order) on fp32 features
 
 and the cluster assignments must be identical; then a fixed caption table goes through the HIP BERT-large CLS encoder + cosine top-k
 and through torch_ref's fp32 BERT + the oracle top-k, and the retrieved indices / the tree-search path must be identical.  The

@@ -45,7 +45,7 @@ def test_shipped_merge_T400_cluster_assignments_identical(c2):
     assert np.array_equal(h["labels"], c["labels"]), "merge cluster assignments differ between the HIP path and the CPU reference path"
     assert h["exit_iter"] == c["exit_iter"]
     assert c["exit_iter"] >= 2 and m.min() < 0.5          # boundaries are decided by real distance comparisons, not by scene cuts
-    # the HIP k-means on ITS OWN (fp16) features against the oracle on the same fp16 bits: bit-exact labels (SC-KM1), as everywhere else
+    # the HIP k-means on ITS OWN (fp16) features against the oracle on the same fp16 bits: bit-exact labels (SC-KM2), as everywhere else
     X16 = c2["feats"][:400].reshape(400, -1).cpu().numpy()
     import torch
     torch.manual_seed(0)

@@ -55,6 +55,38 @@ def test_overlapped_session_equals_serial_session():
             assert ra[k] == rb[k], (ra["segment"], k, ra[k], rb[k])
         assert len(ra["tokens"]) == 24 and len(ra["short"]) == 5
     assert any(r["retrieved_rows"] for r in a) and a[1]["context"] > 16 * 5           # something was retrieved and spliced
+    # GPU time lines (round 6): both runs know when each side's job ran on the GPU; serially the two sides never execute together
+    ca, cb = SS.StreamingSession.co_running(a), SS.StreamingSession.co_running(b)
+    assert ca["co_running_fraction"] == 0.0 and 0.0 <= cb["co_running_fraction"] <= 1.0
+    assert all(r["gpu_ms"]["mfma"][0] <= r["gpu_ms"]["mfma"][1] <= r["gpu_ms"]["decode"][0] <= r["gpu_ms"]["decode"][1] for r in a + b)
+
+
+def test_a_failing_decode_fails_fast_instead_of_waiting_for_its_slot():
+    """after the first error a worker skips the queued jobs - their bookkeeping (slot release, pending count) must still run, so the
+    reader / updater side raises from results() at once instead of waiting 600 s for a KV-cache slot nobody frees."""
+    import time
+    dev = torch.device("cuda:0")
+    enc, model, bert = _build(dev)
+    s = SS.StreamingSession(model, enc, bert, T.HashTokenizer(vocab=2048, max_len=64), _Tok(), MEM, TC.PositionCaptioner(dev), synthetic.SyntheticTokenizer(),
+                            overlap=True, decode_cus=96, max_new_tokens=8, max_context=2048)
+    u8 = torch.from_numpy(TC.crossfade_stream(4 * 40, seed=78, period=8, h=56, w=56)).to(dev)
+
+    def boom(*a, **k):
+        raise RuntimeError("decode failed on purpose")
+    s.graphs[0].run = boom                                       # the answer of segment 0 (slot 0) fails
+    t0 = time.time()
+    for i in range(4):
+        try:
+            s.submit(u8[i * 40:(i + 1) * 40], f"segment {i}: what happened")
+        except RuntimeError:
+            break
+    try:
+        s.results()
+        raised = False
+    except RuntimeError as e:
+        raised = "on purpose" in str(e) or "has failed" in str(e)
+    s.close()
+    assert raised and time.time() - t0 < 120
     print("\n[session] 4 segments x 40 frames, 24 tokens each: overlapped == serial;", [r["context"] for r in a], a[-1]["tokens"][:8])
 
 
