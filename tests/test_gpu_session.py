@@ -59,6 +59,7 @@ def test_overlapped_session_equals_serial_session():
     ca, cb = SS.StreamingSession.co_running(a), SS.StreamingSession.co_running(b)
     assert ca["co_running_fraction"] == 0.0 and 0.0 <= cb["co_running_fraction"] <= 1.0
     assert all(r["gpu_ms"]["mfma"][0] <= r["gpu_ms"]["mfma"][1] <= r["gpu_ms"]["decode"][0] <= r["gpu_ms"]["decode"][1] for r in a + b)
+    print("\n[session] 4 segments x 40 frames, 24 tokens each: overlapped == serial;", [r["context"] for r in a], a[-1]["tokens"][:8])
 
 
 def test_a_failing_decode_fails_fast_instead_of_waiting_for_its_slot():
@@ -87,7 +88,6 @@ def test_a_failing_decode_fails_fast_instead_of_waiting_for_its_slot():
         raised = "on purpose" in str(e) or "has failed" in str(e)
     s.close()
     assert raised and time.time() - t0 < 120
-    print("\n[session] 4 segments x 40 frames, 24 tokens each: overlapped == serial;", [r["context"] for r in a], a[-1]["tokens"][:8])
 
 
 def test_worker_reraises_on_the_callers_thread():
@@ -124,3 +124,20 @@ def test_move_to_stream_when_switches_at_the_next_launch_and_keeps_the_order():
     torch.cuda.synchronize()
     ref = torch.nn.functional.rms_norm(y.float(), (1024,), g.float(), 1e-6)          # from the FINAL y: b must have waited for it
     assert (b.float() - ref).abs().max().item() < 2e-2 and torch.isfinite(a.float()).all()
+
+
+def test_host_frames_go_through_the_reader_thread_and_give_the_same_session():
+    """round 6: a segment's frames may live on the HOST (numpy / CPU tensor / a decoder's frames); the reader stage is then
+    ingest.AsyncFrameIngest (producer thread -> pinned staging -> H2D on a copy stream -> encode) inside the MFMA job.  Same records as with
+    device-resident frames, serially and overlapped."""
+    dev = torch.device("cuda:0")
+    u8 = TC.crossfade_stream(3 * 40, seed=79, period=8, h=56, w=56)
+    questions = [f"segment {i}: " + " ".join(synthetic.caption(i + 1).split()[2:14]) for i in range(3)]
+    on_dev = [torch.from_numpy(u8[i * 40:(i + 1) * 40]).to(dev) for i in range(3)]
+    on_host = [u8[i * 40:(i + 1) * 40] for i in range(3)]                          # numpy uint8
+    a = _run(False, on_dev, questions, 12)
+    b = _run(True, on_host, questions, 12)
+    c = _run(False, [torch.from_numpy(x) for x in on_host], questions, 12)         # CPU tensors, serial
+    for ra, rb, rc in zip(a, b, c):
+        for k in ("short", "path_text", "retrieved_rows", "retrieved_crc", "context", "first_token", "tokens"):
+            assert ra[k] == rb[k] == rc[k], (ra["segment"], k)

@@ -17,7 +17,7 @@ def per_kernel(path, counter):
         a = out.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += v
     return out
 
-FAMILIES = {"k_gemm_all": "k_gemm", "k_gemm256": "k_gemm256", "k_attn_dh128_causal": "k_attnILi128ELi", "k_attn_dh64": "k_attnILi64ELi", "km_assign": "km_assign", "km_update": "km_update"}
+FAMILIES = {"k_gemm_all": "k_gemm", "k_gemm256": "k_gemm256", "k_attn_dh128_causal": "k_attnILi128ELi", "k_attn_dh64": "k_attnILi64ELi", "km_assign": "km_assign", "km_update": "km_update", "km2_pass": "km2_pass"}
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
 for fam, pat in FAMILIES.items():
