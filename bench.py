@@ -807,6 +807,14 @@ def main():
                            weights="random-init", launcher="self (bare command)" if os.environ.get("SC_BENCH_SELF_LAUNCHED") == "1" else
                            ("torch.distributed.run" if world > 1 else "single process")),
                roofline=roof, roofline_stages=stages, stages=per, power=power.summary(), build=ops.build_info())
+    # rounds are compared on boxes whose chips hold 1.74 - 1.93 GHz under the same 1400 W cap (+-4 % on `value`): the MFMA-bound share of the
+    # step (GEMM + attention launches of the encode and the prefill) rescaled to a 1900 MHz shader clock, the rest left as measured
+    pw = out.get("power") or {}
+    if pw.get("sclk_mhz_avg"):
+        mfma_ms = sum(v["ms_per_step"] for k, v in per.items() if k.split("/")[0] in ("encode", "prefill") and k.split("/")[1] in ("k_gemm", "k_attn"))
+        at1900 = mfma_ms * pw["sclk_mhz_avg"] / 1900.0 + (ms_step - mfma_ms)
+        out["value_at_1900MHz"] = dict(value=round(n_total / at1900 * 1e3, 2), ms_per_step=round(at1900, 3), mfma_bound_ms_per_step=round(mfma_ms, 3), sclk_mhz_avg=pw["sclk_mhz_avg"],
+                                       note="value with the MFMA-bound launches rescaled by sclk_avg / 1900 MHz: the figure to compare between boxes and rounds; `value` is what was measured")
     if pipe.last.get("path_text") is not None:      # what the question retrieved (and, on the sharded path, which global frames): equal for every GPU count
         import zlib
         sig = json.dumps(dict(path_text=list(pipe.last["path_text"]), wanted=pipe.last.get("wanted")))
