@@ -56,7 +56,9 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *   7  round 6: - sc_set_cu_budget (the one piece of process-wide mutable state in the library: a CU-masked stream has carried its own CU
  *      count since version 5, and that is the only way a persistent launch is sized now - "no global state besides the thread-local error
  *      text" holds again); k-means: reduction spec SC-KM2 (labels of non-tied inputs unchanged; centroids / fp64 distances differ from
- *      version 6's in the last bits), workspace layout changed (sc_kmeans_workspace_bytes says how much, as always)
+ *      version 6's in the last bits), workspace layout changed (sc_kmeans_workspace_bytes says how much, as always);
+ *      + sc_counter_uniform_f32 (the uniform draw of the n-th sampled token as a pure function of (seed, n): batched == one-by-one and
+ *      graph == eager under sampling, no generator state on the device)
  */
 #define SC_ABI_VERSION 7
 
@@ -301,6 +303,11 @@ int sc_decode_qkv_f16(const void* Wq, const void* Wkv, const void* bq, const voi
  * captured decode graph (llm.DecodeGraph). */
 int sc_decode_advance(const int64_t* next_token, int64_t* ring, int64_t* ring_index, int32_t* token, int32_t* pos, int32_t* kv_len,
                       int32_t* n_prev, sc_stream_t stream);
+/* v7: u[b] = uniform in [0, 1) = splitmix64(seeds[b] + (counter[0] + counter_add) * 0x9E3779B97F4A7C15) >> 40, scaled by 2^-24.  seeds [B] device
+ * int64; counter: device int64 scalar or NULL (= 0).  The draw of the n-th sampled token of a sequence depends on its seed and n alone (HF draws
+ * from the default generator in batch order, reference call sites inference_streaming_longva_v2.py:252-256, utiles.py:551-556: a batched
+ * generate there is not the same random experiment as one-by-one generates; here it is). */
+int sc_counter_uniform_f32(const int64_t* seeds, int B, const int64_t* counter, int64_t counter_add, float* u, sc_stream_t stream);
 size_t sc_pick_token_workspace_bytes(int B);
 int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out,
                       void* ws, size_t ws_bytes, sc_stream_t stream);

@@ -69,12 +69,15 @@ def parse_args(argv=None):
     p.add_argument("--tiny", action="store_true", help="tiny random-init architectures (smoke runs)")
     p.add_argument("--synthetic_breakpoints", type=int, default=2, help="questions per synthetic video (one every 60 s)")
     p.add_argument("--max_new_tokens", type=int, default=256)
-    p.add_argument("--batch_captions", action="store_true", help="caption all chunks of an update with one batched generate (SURVEY 8(f).1)")
-    p.add_argument("--overlap", type=int, nargs="?", const=128, default=0, metavar="DECODE_CUS",
+    p.add_argument("--batch_captions", type=int, nargs="?", const=1, default=1, metavar="0|1",
+                   help="caption all chunks of an update with one batched generate (SURVEY 8(f).1; default since round 6: a sequence samples the same "
+                        "tokens batched or alone - per-sequence seeds - so the batch is only faster); 0 = one generate per chunk as the reference does")
+    p.add_argument("--overlap", type=int, nargs="?", const=128, default=128, metavar="DECODE_CUS",
                    help="reader / updater of the NEXT segment on a second host thread and CU partition while the answer is decoded on DECODE_CUS CUs "
                         "(multiples of 32; the reference's three-thread design, previous_version/streaming_demo_llava_next_3.py:967-991; SURVEY 8(f).3).  "
-                        "Greedy outputs are identical to the serial run; SAMPLED outputs (temperature > 0) are not reproducible from a seed in this mode: "
-                        "the answer and the next segment's captions draw from the device's one default generator in whatever order the two threads reach it")
+                        "ON by default since round 6 (`--overlap 0`: one stage after the other on the whole chip, as the reference's batch entry point). "
+                        "Same outputs as the serial run, greedy AND sampled: every sequence samples from its own seed (answers and captions take their "
+                        "seeds from two separate generators seeded from torch.manual_seed), nothing is drawn from a generator shared by the two threads")
     p.add_argument("--memory_tree_dir", type=str, default=None,
                    help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
     args = p.parse_args(argv)
@@ -236,9 +239,21 @@ def run_inference(args):
         all_annotations = json.load(open(args.annotations, "r"))
     inference_count = 0
     look = Lookahead(model, args.overlap, main_device) if args.overlap else None
+    # Sampling seeds by ROLE (round 6): the answers draw their per-sequence seeds from one CPU generator, the chunk captions / merge summaries
+    # from another (`llm.draw_seeds`; the n-th token of a sequence is a pure function of its seed and n).  Caption calls are sequential whether
+    # they run on this thread or on the look-ahead thread, answer calls likewise, so a seeded run samples the same tokens serially and with
+    # --overlap, with and without --batch_captions - the two threads share no generator state.  `captioner` is a view of the
+    # model for that role: same weights, same KV cache as `model` (the serial path captions with the model itself, as the reference's second
+    # replica does, :697-700); the look-ahead thread's view has a cache of its own and shares the role's seed generator.
+    base_seed = torch.initial_seed()
+    model.seed_generator = torch.Generator().manual_seed((base_seed ^ 0x5DEECE66D) & (2 ** 62 - 1))
+    captioner = LM.LlavaQwenForCausalLM(model.lm, model.frame_encoder, model.eos_token_id)
+    captioner.generation_config, captioner.config = model.generation_config, model.config
+    captioner.seed_generator = torch.Generator().manual_seed((base_seed ^ 0x2545F4914F6CDD1D) & (2 ** 62 - 1))
     if look is not None:
         import copy
         look.tokenizer = copy.deepcopy(tokenizer)           # a HF fast tokenizer is not re-entrant: the look-ahead thread encodes with a copy of its own
+        look.captioner.seed_generator = captioner.seed_generator
     for anno in all_annotations:
         os.makedirs(args.memory_basic_dir, exist_ok=True)
         args.memory_file = "memory_{}.json".format(inference_count)
@@ -288,7 +303,7 @@ def run_inference(args):
             if ahead is not None:
                 feature_bank, long_memory_tree, short_memory_buffer = ahead
             else:
-                feature_bank, long_memory_tree, short_memory_buffer = read_and_update(star, end, long_memory_tree, short_memory_buffer, model)
+                feature_bank, long_memory_tree, short_memory_buffer = read_and_update(star, end, long_memory_tree, short_memory_buffer, captioner)
             gen_kw = {}
             if look is not None and si + 1 < len(segments):
                 # the next segment's reader / updater start when this answer's prefill is done, and the answer's token loop runs on the decode

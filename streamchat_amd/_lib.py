@@ -58,6 +58,7 @@ SIGNATURES = {
     "sc_rope_qk_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_rope_row_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "sc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sc_counter_uniform_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "sc_pick_token_workspace_bytes": (c_size_t, [c_int]),
     "sc_pick_token_f32": (c_int, [c_void_p, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sc_sample_token_workspace_bytes": (c_size_t, [c_int]),

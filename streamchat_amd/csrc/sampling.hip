@@ -419,6 +419,29 @@ extern "C" int sc_decode_advance(const int64_t* next_token, int64_t* ring, int64
     return SC_OK;
 }
 
+namespace {
+// u[b] = a uniform in [0, 1) that is a pure function of (seeds[b], n), n = counter[0] + counter_add: splitmix64 of seed + n * golden, top 24 bits.
+// The n-th sampled token of a sequence draws the same number whether the sequence is decoded alone or in a batch, eagerly or from a replayed
+// graph, on whichever host thread: nothing is read from (or advanced in) a generator on the device.
+__global__ void k_counter_uniform(const int64_t* __restrict__ seeds, const int64_t* __restrict__ counter, int64_t add, int B, float* __restrict__ u) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long n = (unsigned long long)((counter ? counter[0] : 0) + add);
+    unsigned long long x = (unsigned long long)seeds[b] + n * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    u[b] = (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+}  // namespace
+
+extern "C" int sc_counter_uniform_f32(const int64_t* seeds, int B, const int64_t* counter, int64_t counter_add, float* u, sc_stream_t stream) {
+    SC_REQUIRE(seeds && u && B > 0, "sc_counter_uniform_f32: null pointer argument or B <= 0");
+    hipLaunchKernelGGL(k_counter_uniform, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, seeds, counter, counter_add, B, u);
+    SC_CHECK_LAUNCH("sc_counter_uniform_f32");
+    return SC_OK;
+}
+
 extern "C" size_t sc_pick_token_workspace_bytes(int B) { return B > 0 ? (size_t)B * NBLK * sizeof(Part) : 0; }
 
 extern "C" int sc_pick_token_f32(const float* logits, int B, int V, int64_t ld, float temperature, const float* u, int64_t* out, void* ws,

@@ -300,6 +300,28 @@ import threading as _threading
 _GEN_LOCK = _threading.RLock()
 
 
+# Round 6: SAMPLING draws nothing from a generator on the device any more.  Every sequence gets a 63-bit SEED when its generate starts and the
+# uniform of its n-th sampled token is `ops.counter_uniform(seed, n)` - a pure function (sampling.hip, sc_counter_uniform_f32).  So a sequence
+# samples the same tokens decoded alone or in a batch (BatchDecoder), eagerly or from a replayed hipGraph, and whatever another host thread
+# is sampling at the same moment (session.py, the entry point's --overlap: ADVICE r05).  Seeds come, in call order, from `seed=` (explicit), a
+# `generator` (CPU or CUDA), the model object's `seed_generator` (a CPU torch.Generator of its own: one per role in the entry point), or torch's
+# default CPU generator (`torch.manual_seed` seeds it).  _GEN_LOCK is still taken around graph CAPTURES: torch puts the device's default
+# generator into capture mode whether or not the graph draws from it.
+def draw_seeds(B, generator=None, seed=None):
+    """[B] int64 CPU tensor of per-sequence seeds"""
+    if seed is not None:
+        sd = torch.as_tensor(seed, dtype=torch.int64).reshape(-1)
+        if sd.numel() == 1 and B > 1:
+            sd = sd + torch.arange(B, dtype=torch.int64) * 0x632BE5AB            # one explicit seed for a batch: a distinct stream per sequence
+        if sd.numel() != B:
+            raise ValueError(f"draw_seeds: {sd.numel()} seeds for {B} sequences")
+        return sd.clone()
+    if generator is not None and generator.device.type != "cpu":
+        with _GEN_LOCK:
+            return torch.randint(0, 2 ** 62, (B,), generator=generator, device=generator.device).cpu()
+    return torch.randint(0, 2 ** 62, (B,), generator=generator)
+
+
 class Sampling(typing.NamedTuple):
     """What turns logits into the next token: HF's processor chain as `generate` builds it (transformers generation/utils.py
     _get_logits_processor / _get_logits_warper): repetition penalty always, temperature / top-k / top-p only when sampling."""
@@ -345,7 +367,7 @@ class DecodeGraph:
 
     def __init__(self, lm, max_new_tokens=1024, nsplit=None, temperature=0.0, sampling=None):
         self.sampling = sampling if sampling is not None else Sampling(float(temperature))
-        self.temperature = self.sampling.temperature    # > 0: sample; the uniform draw is a graph-safe torch.rand inside the graph
+        self.temperature = self.sampling.temperature    # > 0: sample; the uniform of token n is counter_uniform(seed, n): a pure function, graph-safe
         self.nsplit = nsplit if nsplit else decode_nsplit(lm.cfg.head_dim, lm.cache_len)
         self.lm = lm
         dev = lm.device
@@ -365,6 +387,8 @@ class DecodeGraph:
                                    dtype=torch.uint8, device=dev)
         self.ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(1), 256), dtype=torch.uint8, device=dev)
         self.nxt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)                      # the sequence's sampling seed (start())
+        self.u = torch.zeros(1, dtype=torch.float32, device=dev)
         self.q_buf = torch.empty(c.heads * c.head_dim, dtype=torch.float16, device=dev)
         self.tab_q, self.tab_k = lm.rope_tabs(lm.cache[0].shape[0] if lm.cache is not None else None)      # fp32 rotary tables the graph reads by pointer
         self._captured_ptrs = None
@@ -395,7 +419,7 @@ class DecodeGraph:
             h = ops.gemv(L["wd"], m, None, residual=h2).view(1, -1)
         logits = ops.gemv(lm.lm_head, h, None, out_f32=True, rms_gamma=lm.norm, rms_eps=c.eps)
         sp = self.sampling                                                   # HIP next-token kernels over the 152 064 logits (sampling.hip)
-        u = torch.rand(1, device=lm.device) if sp.temperature > 0 else None
+        u = ops.counter_uniform(self.seed, self.cnt, 1, out=self.u) if sp.temperature > 0 else None      # token n = cnt + 1 (the first was picked by the caller)
         if sp.plain:
             nxt = ops.pick_token(logits, sp.temperature, u, out=self.nxt, ws=self.ws_pick)
         else:
@@ -404,20 +428,15 @@ class DecodeGraph:
         ops.decode_advance(nxt, self.out, self.cnt, self.tok, self.pos, self.len, self.nprev)     # ring append + the five counters: one launch
         return logits
 
-    def start(self, first_token: int):
-        """position the graph right after the prefill: next input token = first_token, cache length = lm.cache_len"""
+    def start(self, first_token: int, seed: int = 0):
+        """position the graph right after the prefill: next input token = first_token, cache length = lm.cache_len; `seed`: the sequence's
+        sampling seed (its first token was drawn with n = 0 by the caller, the graph draws n = 1, 2, ..)"""
         self.tok.fill_(int(first_token)); self.pos.fill_(self.lm.cache_len); self.len.fill_(self.lm.cache_len + 1); self.cnt.zero_()
-        self.hist[0] = int(first_token); self.nprev.fill_(1)
+        self.hist[0] = int(first_token); self.nprev.fill_(1); self.seed.fill_(int(seed))
 
     def capture(self):
-        # the warm-up step and the capture itself draw from the default CUDA generator when sampling: put its state back afterwards, so
-        # that the tokens of a seeded run do not depend on whether the graph already existed
-        with _GEN_LOCK:
-            rng_state = torch.cuda.get_rng_state(self.lm.device)
-            try:
-                self._capture()
-            finally:
-                torch.cuda.set_rng_state(rng_state, self.lm.device)
+        with _GEN_LOCK:                 # (the capture puts the device's default generator into capture mode: see _GEN_LOCK)
+            self._capture()
 
     def _capture(self):
         snap = (self.tok.clone(), self.pos.clone(), self.len.clone(), self.cnt.clone(), self.nprev.clone())
@@ -452,11 +471,7 @@ class DecodeGraph:
             for r in range(step):
                 if r % 32 == 0:
                     ops.stream_ptr(self.lm.device)          # (a pending ops.move_to_stream_when of this thread takes effect between replays)
-                if self.temperature > 0:
-                    with _GEN_LOCK:                         # the graph draws from the default generator
-                        self.graph.replay()
-                else:
-                    self.graph.replay()
+                self.graph.replay()
             done += step
             if eos:
                 toks = self.out[:done].cpu().tolist()
@@ -531,31 +546,30 @@ class BatchDecoder:
         self.len += 1
         return ops.gemm(ops.rmsnorm(h, lm.norm, c.eps), lm.lm_head, None, out_f32=True)
 
-    def _pick(self, logits, sp, generator=None):
+    def _pick(self, logits, sp, counter=None):
         """next token per sequence on the device (sampling.hip): HF's processor chain of `sp` over the ids each sequence generated so far
-        (self.hist[b, :nprev]); the uniform draws come from `generator` (the default CUDA generator inside a captured graph)"""
-        if sp.temperature > 0:
-            with _GEN_LOCK:
-                u = torch.rand(logits.shape[0], device=logits.device, generator=generator)
-        else:
-            u = None
+        (self.hist[b, :nprev]); the uniform of sequence b's n-th token is counter_uniform(seed[b], n), n = counter[0] (None: 0, the first token)"""
+        u = ops.counter_uniform(self.seed, counter, 0, out=self._u) if sp.temperature > 0 else None
         if sp.plain:
             return ops.pick_token(logits, sp.temperature, u, ws=self._ws_pick)
         return ops.sample_token(logits, sp.temperature, u, sp.top_k, sp.top_p, sp.repetition_penalty, prev_ids=self.hist, n_prev=self.nprev, ws=self._ws_pick)
 
     def _graph_body(self, sp):
         logits = self.step(self.tok)
-        nxt = self._pick(logits, sp)
+        nxt = self._pick(logits, sp, self.cnt)                 # cnt = the index of the token being drawn (1 after the first)
         self.hist.index_copy_(1, self.cnt, nxt.view(-1, 1))
         self.tok.copy_(nxt)
         self.cnt.add_(1); self.nprev.add_(1)
 
-    def generate(self, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, generator=None, use_graph=True, sampling=None):
+    def generate(self, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, generator=None, use_graph=True, sampling=None, seed=None):
         """Returns a list of B python lists of new token ids (each cut at its first EOS, EOS included like HF).  The decode step is
-        captured once as a hipGraph and replayed (the ~340 launches of a step are launch-bound from Python); sampling inside the
-        graph draws from the default CUDA generator, so a user `generator` selects the eager path.  EOS is checked on the host
-        every 16 steps (sequences that are done keep stepping; their extra tokens are dropped)."""
+        captured once as a hipGraph and replayed (the ~340 launches of a step are launch-bound from Python).  Sampling: sequence b draws
+        counter_uniform(seed[b], n) for its n-th token (`draw_seeds`: `seed`, `generator` or torch's default CPU generator, in that order) -
+        the tokens a sequence samples do not depend on what it is batched with.  EOS is checked on the host every 16 steps (sequences that
+        are done keep stepping; their extra tokens are dropped)."""
         B, dev = self.B, self.lm.device
+        self.seed = draw_seeds(B, generator, seed).to(dev)
+        self._u = torch.zeros(B, dtype=torch.float32, device=dev)
         sp = sampling if sampling is not None else Sampling(float(temperature) if do_sample and temperature > 0 else 0.0)
         eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else (set() if eos_token_id is None else {eos_token_id})   # HF allows a list
         longest = int(self.len.max().item()) + max_new_tokens
@@ -570,13 +584,13 @@ class BatchDecoder:
         self._row0 = torch.arange(B, device=dev, dtype=torch.int64) * self.cap
         self.hist = torch.zeros((B, max_new_tokens), dtype=torch.int64, device=dev)      # generated ids per sequence (the repetition penalty's set)
         self.nprev = torch.zeros(B, dtype=torch.int32, device=dev)
-        first = self._pick(self.logits, sp, generator)
+        first = self._pick(self.logits, sp, None)
         self.hist[:, 0] = first
         self.nprev.fill_(1)
         self.tok = first.to(torch.int32).contiguous()
         self.cnt = torch.ones(1, dtype=torch.int64, device=dev)
         graph = None
-        if use_graph and generator is None and max_new_tokens > 2:
+        if use_graph and max_new_tokens > 2:
             state = (self.tok, self.len, self.cnt, self.hist, self.nprev)
             snap = tuple(t.clone() for t in state)
             s = torch.cuda.Stream(device=dev)
@@ -593,13 +607,9 @@ class BatchDecoder:
         steps = 1
         while steps < max_new_tokens:
             if graph is not None:
-                if sp.temperature > 0:
-                    with _GEN_LOCK:
-                        graph.replay()
-                else:
-                    graph.replay()
+                graph.replay()
             else:
-                nxt = self._pick(self.step(self.tok), sp, generator)
+                nxt = self._pick(self.step(self.tok), sp, self.cnt)
                 self.hist[:, steps] = nxt
                 self.tok.copy_(nxt)
                 self.cnt.add_(1); self.nprev.add_(1)
@@ -675,20 +685,18 @@ class LlavaQwenForCausalLM:
         dec = BatchDecoder(self.lm, prompts, max_new_tokens)
         if stats:
             torch.cuda.synchronize(); t1 = time.perf_counter()
-        toks = dec.generate(max_new_tokens, eos_token_id=self.eos_token_id, generator=generator, sampling=sp)
+        seeds = draw_seeds(len(prompts), generator if generator is not None else getattr(self, "seed_generator", None), kwargs.get("seed"))
+        toks = dec.generate(max_new_tokens, eos_token_id=self.eos_token_id, sampling=sp, seed=seeds)
         if stats:
             torch.cuda.synchronize(); t2 = time.perf_counter()
             self.batch_stats = dict(prompt_tokens=[int(e.shape[0]) for e in prompts], prefill_s=t1 - t0, decode_s=t2 - t1, steps_run=dec.steps_run,
                                     new_tokens=sum(len(t) for t in toks), nsplit=dec.nsplit)
         return [torch.tensor([t], dtype=torch.long, device=self.device) for t in toks]
 
-    def _next(self, logits, sp, prev, generator=None):
-        """one token from the last-row logits through the processor chain of `sp`; prev = ids generated so far (python list)"""
-        if sp.temperature > 0:
-            with _GEN_LOCK:
-                u = torch.rand(1, device=self.device, generator=generator)
-        else:
-            u = None
+    def _next(self, logits, sp, prev, seed=0):
+        """one token from the last-row logits through the processor chain of `sp`; prev = ids generated so far (python list); the uniform
+        of token n = len(prev) is counter_uniform(seed, n)"""
+        u = ops.counter_uniform(torch.tensor([int(seed)], dtype=torch.int64, device=self.device), None, len(prev)) if sp.temperature > 0 else None
         if sp.plain:
             return int(ops.pick_token(logits, sp.temperature, u).item())
         pv = torch.tensor([prev if prev else [0]], dtype=torch.int64, device=self.device)
@@ -709,10 +717,11 @@ class LlavaQwenForCausalLM:
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
         eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])
+        seed = int(draw_seeds(1, generator if generator is not None else getattr(self, "seed_generator", None), kwargs.get("seed"))[0]) if sp.temperature > 0 else 0
         if max_new_tokens > 1 and generator is None and kwargs.get("decode_graph", True):
-            # the token loop runs as a replayed hipGraph for greedy AND for sampling (the uniform draws come from the default CUDA
-            # generator inside the graph); a user `generator` selects the eager loop below
-            first = self._next(logits, sp, [])
+            # the token loop runs as a replayed hipGraph for greedy AND for sampling (token n draws counter_uniform(seed, n) inside the graph);
+            # a user `generator` (it only seeds) or decode_graph=False select the eager loop below: same tokens
+            first = self._next(logits, sp, [], seed)
             if first in eos:
                 return torch.tensor([[first]], dtype=torch.long, device=self.device)
             key = tuple(round(float(v), 6) for v in sp)
@@ -720,7 +729,7 @@ class LlavaQwenForCausalLM:
             if dg is None or dg.out.numel() < max_new_tokens or not dg.valid():
                 dg = self._dgs[key] = DecodeGraph(self.lm, max_new_tokens=max(max_new_tokens, 256), sampling=sp)
             self._dg = dg
-            dg.start(first)
+            dg.start(first, seed)
             # round 5 (the entry point's --overlap): the prefill is done and its first token is on the host - `on_prefill_done`
             # lets the caller start the next segment's reader / updater on another host thread, and the HBM-bound token loop moves to
             # `decode_stream` (a CU partition of its own) so that the two run beside each other.  Same kernels, same tokens.
@@ -738,7 +747,7 @@ class LlavaQwenForCausalLM:
             return torch.tensor([[first] + rest], dtype=torch.long, device=self.device)
         new = []
         for step in range(max_new_tokens):
-            tok = self._next(logits, sp, new, generator)
+            tok = self._next(logits, sp, new, seed)
             new.append(tok)
             if tok in eos:
                 break

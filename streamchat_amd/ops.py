@@ -236,6 +236,31 @@ def sim_topk(q: torch.Tensor, docs: torch.Tensor, k: int = 1, metric: str = "cos
     return idx, score
 
 
+def counter_uniform(seeds: torch.Tensor, counter=None, add: int = 0, out=None):
+    """u [B] fp32 in [0, 1): a pure function of (seeds[b], counter[0] + add) - sc_counter_uniform_f32.  seeds [B] int64 (device); counter: device
+    int64 scalar tensor or None.  No generator state: graph-capturable, the same numbers eagerly, in a graph and on any thread."""
+    _require_cuda(seeds)
+    if seeds.dtype != torch.int64 or (counter is not None and counter.dtype != torch.int64):
+        raise StreamChatHipError("counter_uniform: int64 seeds / counter expected")
+    seeds = seeds.contiguous().view(-1)
+    B = seeds.numel()
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=seeds.device)
+    with torch.cuda.device(seeds.device):
+        check(_lib.load().sc_counter_uniform_f32(ptr(seeds), B, ptr(counter), c_int64(int(add)), ptr(out), stream_ptr(seeds.device)), "sc_counter_uniform_f32")
+    return out
+
+
+def counter_uniform_host(seed: int, n: int) -> float:
+    """the same number on the host (tests; documentation of the formula)"""
+    M = (1 << 64) - 1
+    x = (seed + n * 0x9E3779B97F4A7C15) & M
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M
+    x ^= x >> 31
+    return (x >> 40) / 16777216.0
+
+
 def pick_token(logits: torch.Tensor, temperature: float = 0.0, u=None, out=None, ws=None):
     """Next token ids [B] int64 from fp32 logits [B, V] (or [V]): arg-max (temperature <= 0, lowest index on ties) or a sample from
     softmax(logits / temperature) at the uniform draws `u` [B] (device fp32 in [0, 1)).  No host sync; graph-capturable when `ws`

@@ -37,23 +37,29 @@ def test_parse_args_has_reference_flags():
         assert getattr(a, k) == v
 
 
-def test_overlap_flag_gives_the_same_answers_and_memory(tmp_path, monkeypatch):
+@pytest.mark.parametrize("sampled", [False, True])
+def test_overlap_flag_gives_the_same_answers_and_memory(tmp_path, monkeypatch, sampled):
     """--overlap: the next segment's reader / updater on a second host thread + CU partition while the answer is decoded on its own
-    partition.  With every generate forced greedy (the reference samples: Q12) the answers, the dialogue memory and the persisted memory tree equal
-    those of the serial run."""
+    partition.  The answers, the dialogue memory and the persisted memory tree equal those of the serial run - with every generate forced greedy
+    AND (round 6) with the reference's own sampling settings (temperature 0.2 answers, 0.1 captions): every sequence samples from its own seed,
+    answers and captions take their seeds from two role generators, nothing is drawn from state the two threads share.  Per-chunk captioning
+    (--batch_captions 0) gives the same run again."""
     import torch
     import inference_streaming_longva_v2 as E
     from streamchat_amd import llm as LM
     from streamchat_amd.persistence import load_memory_tree
-    real = LM.resolve_sampling
-    monkeypatch.setattr(LM, "resolve_sampling", lambda *a, **k: LM.Sampling(0.0, 0, 1.0, real(*a, **k).repetition_penalty))
+    if not sampled:
+        real = LM.resolve_sampling
+        monkeypatch.setattr(LM, "resolve_sampling", lambda *a, **k: LM.Sampling(0.0, 0, 1.0, real(*a, **k).repetition_penalty))
     runs = {}
-    for name, extra in (("serial", []), ("overlap", ["--overlap", "128"])):
+    for name, extra in (("serial", ["--overlap", "0"]), ("overlap", []), ("serial_per_chunk", ["--overlap", "0", "--batch_captions", "0"])):
         d = tmp_path / name
         args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(d / "mem"), "--save_file", str(d / "out.json"),
                              "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "2", "--tiny", "--chunk_size", "4",
                              "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3", "--max_new_tokens", "12",
-                             "--multi_modal_memory", "--memory_tree_dir", str(d / "trees"), "--batch_captions"] + extra)
+                             "--multi_modal_memory", "--memory_tree_dir", str(d / "trees")] + extra)
+        assert args.batch_captions == (0 if name == "serial_per_chunk" else 1)          # batched captioning and the overlap are the defaults since round 6
+        assert args.overlap == (128 if name == "overlap" else 0)
         os.makedirs(d, exist_ok=True)
         import numpy as np, random
         torch.manual_seed(0); np.random.seed(0); random.seed(0)
@@ -64,17 +70,18 @@ def test_overlap_flag_gives_the_same_answers_and_memory(tmp_path, monkeypatch):
                           short=[float(t.float().sum()) for t in short])
     assert len(runs["serial"]["answers"]) == 4
     assert runs["overlap"] == runs["serial"]
+    assert runs["serial_per_chunk"] == runs["serial"]
 
 
 @pytest.mark.parametrize("batched", [False, True])
 def test_overlap_with_the_reference_sampling_settings_runs_to_completion(tmp_path, batched):
-    """--overlap with the reference's own generation settings (temperature 0.2 answers, temperature 0.1 captions: both host threads draw from the
-    default CUDA generator inside their decode graphs, so texts are not comparable - Q12); two videos, three questions each."""
+    """--overlap with the reference's own generation settings (temperature 0.2 answers, temperature 0.1 captions) runs to completion with and
+    without batched captions; two videos, three questions each."""
     import inference_streaming_longva_v2 as E
     args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(tmp_path / "mem"), "--save_file", str(tmp_path / "out.json"),
                          "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "2", "--synthetic_breakpoints", "3", "--tiny",
                          "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3", "--max_new_tokens", "40",
-                         "--multi_modal_memory", "--overlap"] + (["--batch_captions"] if batched else []))
+                         "--multi_modal_memory", "--overlap"] + (["--batch_captions", "1"] if batched else ["--batch_captions", "0"]))
     assert args.overlap == 128
     E.run_inference(args)
     out = json.load(open(tmp_path / "out.json"))

@@ -520,3 +520,57 @@ def test_batched_generation_applies_the_same_processor_chain():
     assert [b[0].tolist() for b in batch] == single and single[0] == single[2]
     plain = LM.LlavaQwenForCausalLM(model.lm).generate_batch_with_image_embedding(prompts, [None] * 3, do_sample=False, max_new_tokens=12)
     assert [b[0].tolist() for b in plain] != single                                       # the penalty really changes these sequences
+
+
+# ---- round 6: per-sequence sampling seeds (sc_counter_uniform_f32) ----
+def test_counter_uniform_kernel_equals_the_host_formula():
+    seeds = torch.tensor([0, 1, 123456789012345, 2 ** 62 - 1, 42], dtype=torch.int64, device="cuda")
+    for n in (0, 1, 2, 1000, 2 ** 33 + 5):
+        cnt = torch.tensor([n], dtype=torch.int64, device="cuda")
+        u = ops.counter_uniform(seeds, cnt, 0).cpu().tolist()
+        u2 = ops.counter_uniform(seeds, None, n).cpu().tolist()
+        ref = [ops.counter_uniform_host(int(sd), n) for sd in seeds.cpu().tolist()]
+        assert u == ref == u2 and all(0.0 <= x < 1.0 for x in u)
+    big = ops.counter_uniform(torch.arange(1 << 16, dtype=torch.int64, device="cuda"), None, 7)
+    assert 0.49 < big.mean().item() < 0.51 and big.min().item() >= 0 and big.max().item() < 1
+
+
+def test_a_sequence_samples_the_same_tokens_alone_batched_eagerly_and_from_a_graph():
+    """temperature sampling with per-sequence seeds: BatchDecoder == one generate per sequence (same seeds), hipGraph == eager loop, a CUDA or
+    CPU `generator` only seeds, and two host threads sampling at the same time do not disturb each other."""
+    import threading
+    d, sd, cfg = _tiny()
+    emb = torch.from_numpy(d["inputs_embeds"]).cuda().half()
+    prompts = [emb, emb[:20], emb[5:30]]
+    lm = LM.Qwen2Model(sd, cfg, max_seq=96)
+    seeds = [11, 222, 3333]
+    sp = LM.resolve_sampling({}, True, 1.5, LM._UNSET, LM._UNSET, LM._UNSET)         # what generate_with_image_embedding resolves: HF's default top_k = 50 included
+    batched = LM.BatchDecoder(lm, prompts, max_new_tokens=10).generate(10, sampling=sp, seed=seeds)
+    batched_eager = LM.BatchDecoder(lm, prompts, max_new_tokens=10).generate(10, sampling=sp, seed=seeds, use_graph=False)
+    assert batched == batched_eager and len({tuple(t) for t in batched}) == 3
+
+    def one(model, e, seed, **kw):
+        model.prepare_inputs_embeddings_for_multimodal = lambda *a, **k: (None, None, None, None, e.unsqueeze(0), None)
+        return model.generate_with_image_embedding(torch.arange(5, 12).unsqueeze(0), image_embeddings=None, do_sample=True, temperature=1.5, max_new_tokens=10,
+                                                   seed=seed, **kw)[0].tolist()
+    m = LM.LlavaQwenForCausalLM(lm)
+    alone = [one(m, e, sdd) for e, sdd in zip(prompts, seeds)]
+    assert alone == batched
+    assert [one(m, e, sdd, decode_graph=False) for e, sdd in zip(prompts, seeds)] == alone
+    # a generator only seeds: CPU generator -> same seeds as draw_seeds gives for it; reproducible
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    want = int(LM.draw_seeds(1, g1)[0])
+    m.prepare_inputs_embeddings_for_multimodal = lambda *a, **k: (None, None, None, None, emb.unsqueeze(0), None)
+    a = m.generate_with_image_embedding(torch.arange(5, 12).unsqueeze(0), image_embeddings=None, do_sample=True, temperature=1.5, max_new_tokens=10, generator=g2)[0].tolist()
+    assert a == one(m, emb, want)
+    # two host threads, two models (shared weights, own caches), sampling concurrently: each reproduces its single-threaded result
+    m2 = LM.LlavaQwenForCausalLM(lm.shared_view(96))
+    solo = [one(m, emb, 5), one(m2, emb[:20], 6)]
+    res = [None, None]
+
+    def work(i, model, e, sdd):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            res[i] = [one(model, e, sdd) for _ in range(6)]
+    th = [threading.Thread(target=work, args=(0, m, emb, 5)), threading.Thread(target=work, args=(1, m2, emb[:20], 6))]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(r == solo[0] for r in res[0]) and all(r == solo[1] for r in res[1])

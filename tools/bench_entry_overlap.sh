@@ -3,7 +3,7 @@
 #   bash tools/bench_entry_overlap.sh [videos] [breakpoints] [max_new_tokens]   -> wall seconds of each run (model build excluded: printed by the script)
 V=${1:-1}; B=${2:-4}; T=${3:-256}; D=$(mktemp -d)
 for mode in serial overlap; do
-  extra=""; [ $mode = overlap ] && extra="--overlap 128"
+  extra="--overlap 0"; [ $mode = overlap ] && extra="--overlap 128"
   python - <<PY
 import json, time, torch, sys
 sys.path.insert(0, ".")
