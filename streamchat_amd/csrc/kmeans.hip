@@ -16,7 +16,7 @@
 // cell needs a cross-lane step when a thread owns a row, so the slab can live in LDS and the pass runs at normal occupancy.
 //
 // Two kernel families, same bits:
-//   km2_pass<K, RGW, MODE>   (fp16 rows, D % 64 == 0, K in {5, 8}, 128 < T + 7 K <= 448)   ONE read of X per Lloyd iteration.
+//   km2_pass<K, RGW, MODE>   (fp16 rows, D % 64 == 0, K in {5, 8}, T >= 120 (K = 5) / 144 (K = 8), T + 7 K <= 448)   ONE read of X per Lloyd iteration.
 //               A workgroup owns a 2048-column group and walks its 32 slices; the [T, 64] fp16 slab of a slice is gathered into LDS by
 //               LDS-DMA (buffer_load ... lds) SORTED BY CLUSTER and used twice - the update of iteration i and, against the C' that
 //               comes out of it, the distances of iteration i + 1.  Every wave owns the same 8-row groups of the slab for the DMA, the
@@ -963,9 +963,15 @@ bool km2_enabled() {
     return on != 0;
 }
 // rows-per-wave bucket: the slab holds RGW * 64 rows and must take the T rows sorted by cluster with every cluster padded to whole 8-row groups.
-// Below ~130 rows a slice is too little work per workgroup step (two barriers, one DMA round trip): the two-pass kernels are as fast at
-// T = 100 and 25 % faster at T = 64, K = 8 (profiles/r06_run_a_kmeans_one_read_pass.md) - those shapes stay on them.
-int km2_rgw(int T, int K) { const int need = T + 7 * K; return need <= 128 ? 0 : need <= 256 ? 4 : need <= 448 ? 7 : 0; }
+// With few rows a slice is too little work per workgroup step (two barriers, one DMA round trip), and the K = 8 instantiation carries 64
+// centroid registers per lane: measured on one box (profiles/r06_run_i_kmeans_T_sweep.jsonl), one-read pass against two-pass kernels, ms per
+// iteration: K = 5: T = 100 0.245 / 0.232, 130 0.269 / 0.288, 200 0.336 / 0.402, 400 0.519 / 0.734; K = 8: T = 64 0.26 / 0.21, 80 0.298 / 0.242,
+// 150 0.360 / 0.387, 392 0.774 / 0.851 - the pass takes over where it wins.
+int km2_rgw(int T, int K) {
+    if (T < (K == 8 ? 144 : 120)) return 0;
+    const int need = T + 7 * K;
+    return need <= 256 ? 4 : need <= 448 ? 7 : 0;
+}
 template <typename Tag>
 bool km2_eligible(const void* X, int T, int64_t D, int K) {
     if (!std::is_same<Tag, ScF16>::value || !km2_enabled()) return false;
