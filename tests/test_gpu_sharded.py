@@ -198,6 +198,7 @@ def test_processes_retrieve_and_prefill_like_one(nproc, launcher):
     assert many["encode_frames_per_s"] > 0 and many["encode_frames_per_s_1gpu_same_job"] > 0 and "SERIAL on rank 0" in many["scaling_note"]
     keys = list(many)
     assert keys.index("encode_frames_per_s") < keys.index("config")       # the encode rate leads the record
+    assert many["dist_warm_up"]["all_gather"] and many["dist_warm_up"]["p2p_peers"] == nproc - 1 and many["dist_warm_up"]["timeout_s"] == 120.0
 
 
 def _full_size_pair(cfg_args, tag):
@@ -270,3 +271,15 @@ def test_bare_command_refuses_more_ranks_than_gpus():
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SC_ALL_RANKS_ON_GPU0")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=base, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "exposes" in r.stderr
+
+
+@pytest.mark.parametrize("nproc", [1, 4])
+def test_preflight_passes_on_a_healthy_job_and_says_what_it_checked(nproc):
+    """`bench.py --gpus N --preflight` (round 6): one JSON line, exit code 0; at N = 4 (torch.distributed.run, every rank on device 0, gloo) the record carries the
+    communicator warm-up (one all-gather + a point-to-point round with each of the 3 peers) and every rank's free HBM; `dist_warm_up` is also in a real N > 1 record."""
+    env = {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"} if nproc > 1 else {}
+    rec = _bench_json(["--config", "C4", "--preflight"] + (["--gpus", str(nproc)] if nproc > 1 else []), env, nproc=nproc, launcher="torchrun")
+    assert rec["preflight"] == "ok" and rec["n_gpus"] == nproc and rec["visible_gpus"] >= 1
+    assert sum(rec["partition_frames_per_rank"]) == 4096 and rec["free_hbm_gb"] > rec["need_hbm_gb"]
+    if nproc > 1:
+        assert rec["collectives"] == dict(world=4, all_gather=True, p2p_peers=3, backend="gloo") and len(rec["free_hbm_gb_per_rank"]) == 4
