@@ -16,7 +16,7 @@
 // cell needs a cross-lane step when a thread owns a row, so the slab can live in LDS and the pass runs at normal occupancy.
 //
 // Two kernel families, same bits:
-//   km2_pass<K, RGW, MODE>   (fp16 rows, D % 64 == 0, K in {5, 8}, T >= 120 (K = 5) / 144 (K = 8), T + 7 K <= 448)   ONE read of X per Lloyd iteration.
+//   km2_pass<K, RGW, MODE>   (fp16 rows, D % 64 == 0, 2 <= K <= 8, T >= 120 (K <= 5) / 144 (K >= 6), T + 7 K <= 448)   ONE read of X per Lloyd iteration.
 //               A workgroup owns a 2048-column group and walks its 32 slices; the [T, 64] fp16 slab of a slice is gathered into LDS by
 //               LDS-DMA (buffer_load ... lds) SORTED BY CLUSTER and used twice - the update of iteration i and, against the C' that
 //               comes out of it, the distances of iteration i + 1.  Every wave owns the same 8-row groups of the slab for the DMA, the
@@ -968,14 +968,14 @@ bool km2_enabled() {
 // iteration: K = 5: T = 100 0.245 / 0.232, 130 0.269 / 0.288, 200 0.336 / 0.402, 400 0.519 / 0.734; K = 8: T = 64 0.26 / 0.21, 80 0.298 / 0.242,
 // 150 0.360 / 0.387, 392 0.774 / 0.851 - the pass takes over where it wins.
 int km2_rgw(int T, int K) {
-    if (T < (K == 8 ? 144 : 120)) return 0;
+    if (T < (K >= 6 ? 144 : 120)) return 0;                                    // (measured at K = 5 and 8; the K between take the nearer one's threshold)
     const int need = T + 7 * K;
     return need <= 256 ? 4 : need <= 448 ? 7 : 0;
 }
 template <typename Tag>
 bool km2_eligible(const void* X, int T, int64_t D, int K) {
     if (!std::is_same<Tag, ScF16>::value || !km2_enabled()) return false;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || D % SW != 0 || !(K == 5 || K == 8)) return false;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || D % SW != 0 || K < 2 || K > 8) return false;     // (the entry point's --num_clusters: 5 as shipped, any K <= 8 takes the pass)
     const int rgw = km2_rgw(T, K);
     if (rgw == 0) return false;
     return (uint64_t)rgw * 64ull * (uint64_t)D * 2ull < (1ull << 32);           // the DMA's 32-bit row offsets (padded rows included)
@@ -1000,8 +1000,11 @@ void km2_launch_k(const void* X, float* Ca, float* Cb, const KmWs& w, const floa
 template <int MODE>
 void km2_launch(const void* X, float* Ca, float* Cb, const KmWs& w, const float* wts, const int32_t* reseed_idx, int n_reseed, int T, int64_t D, int K,
                 hipStream_t s) {
-    if (K == 5) km2_launch_k<5, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s);
-    else km2_launch_k<8, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s);
+    switch (K) {
+#define SC_CASE(n) case n: km2_launch_k<n, MODE>(X, Ca, Cb, w, wts, reseed_idx, n_reseed, T, D, s); break;
+        SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
+#undef SC_CASE
+    }
 }
 
 template <typename Tag>

@@ -32,7 +32,7 @@ def test_kmeans_matches_reference_golden(path):
 @pytest.mark.parametrize("T,D,K", [(40, 512 * 3, 5), (64, 1024 + 8, 8), (37, 520, 3), (50, 100, 4), (300, 2048, 16), (70, 4096, 20)])
 def test_kmeans_bit_exact_vs_oracle(dtype, T, D, K):
     """labels AND centroids bit-identical to the oracle (shared SC-KM2 reduction spec), incl. unaligned D (100)
-    and K > 16 (two centroid tiles).  (40, 1536, 5) and (64, 1032, 8): the lane-mapped kernels; fp16 + D % 64 == 0 + K in {5, 8} takes km2_pass.)"""
+    and K > 16 (two centroid tiles).  (40, 1536, 5) and (64, 1032, 8): the lane-mapped kernels; fp16 + D % 64 == 0 + 2 <= K <= 8 takes km2_pass.)"""
     g = torch.Generator().manual_seed(T * 1000 + D + K)
     centres = torch.randn(max(K - 1, 2), D, generator=g)
     X = (centres[torch.randint(0, centres.shape[0], (T,), generator=g)] + 0.3 * torch.randn(T, D, generator=g)).to(dtype)
@@ -49,10 +49,11 @@ def test_kmeans_bit_exact_vs_oracle(dtype, T, D, K):
 
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("T,D,K", [(23, 64 * 9, 8), (64, 2048 * 3, 8), (90, 2048 + 64 * 5, 5), (128, 4096, 5), (200, 64 * 70, 8),
-                                   (256, 2048 * 2 + 64, 5), (333, 64 * 41, 5), (400, 2048 * 5, 5), (448, 64 * 33, 8)])
+                                   (256, 2048 * 2 + 64, 5), (333, 64 * 41, 5), (400, 2048 * 5, 5), (448, 64 * 33, 8),
+                                   (150, 64 * 21, 2), (230, 2048 + 128, 3), (300, 64 * 50, 4), (180, 64 * 37, 6), (390, 2048 * 2, 7)])
 def test_one_read_pass_bit_exact_vs_oracle(T, D, K, weighted):
-    """km2_pass (fp16, D % 64 == 0, K in {5, 8}, T <= 448: all four (row blocks, Q) instantiations, short last groups, weights, a forced
-    empty cluster) against the oracle: labels, centroids, weights and exit iteration bit-identical."""
+    """km2_pass (fp16, D % 64 == 0, 2 <= K <= 8, T + 7 K <= 448; both slab sizes, short last groups, weights, a forced empty cluster; the small
+    shapes take the two-pass kernels) against the oracle: labels, centroids, weights and exit iteration bit-identical."""
     g = torch.Generator().manual_seed(T * 7 + D + K)
     centres = torch.randn(K + 1, D, generator=g)
     X = (centres[torch.randint(0, K + 1, (T,), generator=g)] + 0.5 * torch.randn(T, D, generator=g)).half()

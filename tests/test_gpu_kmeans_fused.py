@@ -1,4 +1,4 @@
-"""kmeans.hip km2_pass (round 6, the default for fp16 / K in {5, 8} / T <= 448; SC_KM_FUSED=0 switches it off): one pass over X per Lloyd
+"""kmeans.hip km2_pass (round 6, the default for fp16 / 2 <= K <= 8 / T <= 448; SC_KM_FUSED=0 switches it off): one pass over X per Lloyd
 iteration from an LDS-resident slab.  Must equal the two-pass lane-mapped kernels bit for bit - labels, centroids, cluster weights, exit
 iteration - incl. the empty-cluster reseed and the weighted sums (both implement SC-KM2; test_gpu_kmeans.py compares each with the oracle)."""
 import os
