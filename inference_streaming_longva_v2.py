@@ -81,11 +81,12 @@ def parse_args(argv=None):
     p.add_argument("--memory_tree_dir", type=str, default=None,
                    help="persist the visual memory tree of every video here after each question (safetensors + JSON manifest; SURVEY 8(f).4)")
     args = p.parse_args(argv)
-    if args.num_beams != 1:
-        # the reference forwards num_beams to HF generate (:254); this build decodes greedily or by sampling only.  Said HERE, before a model
-        # is loaded and a video is read, not by a NotImplementedError out of the first answer (the shipped script runs num_beams 1,
-        # inference_streamchat_v0.3.sh:20)
-        p.error(f"--num_beams {args.num_beams}: beam search is not implemented in streamchat_amd (greedy / sampling only); use --num_beams 1")
+    if args.num_beams != 1 and (args.temperature or 0) > 0:
+        # the reference forwards num_beams and do_sample = (temperature > 0) to HF generate (:252-256): with both that is HF's beam SAMPLING, which
+        # this build does not have (deterministic beam search it has: streamchat_amd/beam.py).  Said HERE, before a model is loaded and a
+        # video is read, not by a NotImplementedError out of the first answer (the shipped script runs num_beams 1, inference_streamchat_v0.3.sh:20)
+        p.error(f"--num_beams {args.num_beams} with --temperature {args.temperature}: beam sampling is not implemented in streamchat_amd; "
+                f"use --temperature 0 (deterministic beam search, HF semantics) or --num_beams 1")
     return args
 
 

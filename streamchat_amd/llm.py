@@ -492,11 +492,18 @@ class BatchDecoder:
     with M = B, so the 15 GB of weights stream once per step instead of once per sequence, the new K/V rows are scattered with one
     index_copy per layer, and attention is ONE launch per layer over the batch (per-sequence kv_len, split-KV)."""
 
-    def __init__(self, lm, prompts, max_new_tokens):
-        """prompts: list of [n_b, H] fp16 embeddings (image rows already spliced)."""
+    def __init__(self, lm, prompts, max_new_tokens, replicate=None):
+        """prompts: list of [n_b, H] fp16 embeddings (image rows already spliced).  `replicate=N` (beam search): ONE prompt, prefilled once,
+        its cache rows copied into N slots - the N beams of llm.LlavaQwenForCausalLM's beam search start from the same prompt."""
         c = lm.cfg
-        self.lm, self.B = lm, len(prompts)
-        self.cap = max(int(e.shape[0]) for e in prompts) + max_new_tokens
+        if replicate is not None:
+            if len(prompts) != 1:
+                raise ValueError("BatchDecoder(replicate=N) takes exactly one prompt")
+            prompts_all, prompts = [prompts[0]] * int(replicate), prompts
+        else:
+            prompts_all = prompts
+        self.lm, self.B = lm, len(prompts_all)
+        self.cap = max(int(e.shape[0]) for e in prompts_all) + max_new_tokens
         dev = lm.device
         self._rope_tabs = lm.rope_tabs(self.cap)                 # rotary tables cover every position of this batch before a step is captured; the
                                                                  # reference held here keeps them alive if the process-wide cache regrows (ADVICE r03)
@@ -514,6 +521,12 @@ class BatchDecoder:
                 self.len[b] = lm.cache_len
         finally:
             lm.cache, lm.cache_len, lm.max_seq, lm._nsplit_prompt = saved
+        if replicate is not None:                      # slot 0 holds the prompt: the other beams get its K / V rows and its logits
+            n0 = int(self.len[0].item())
+            for cl in self.cache:
+                cl[1:, :n0].copy_(cl[0:1, :n0].expand(self.B - 1, -1, -1))
+            self.len.fill_(n0)
+            first_logits = first_logits * self.B
         # fp32 q | k | v sums of one step: owned here (the decode step is graph-captured; the model's shared scratch may be regrown by a later call)
         self._qkv32 = torch.empty((self.B, (c.heads + 2 * c.kv_heads) * c.head_dim), dtype=torch.float32, device=dev)
         self._q16 = torch.empty((self.B, c.heads * c.head_dim), dtype=torch.float16, device=dev)
@@ -545,6 +558,24 @@ class BatchDecoder:
             h = ops.gemm(m, L["wd"], None, residual=h2)
         self.len += 1
         return ops.gemm(ops.rmsnorm(h, lm.norm, c.eps), lm.lm_head, None, out_f32=True)
+
+    def prepare_steps(self, max_new_tokens):
+        """what `step()` needs when it is driven from outside `generate()` (beam search): the split-KV factor and its workspace"""
+        B, dev, c = self.B, self.lm.device, self.lm.cfg
+        longest = int(self.len.max().item()) + max_new_tokens
+        self.nsplit = getattr(self, "nsplit_override", None) or max(1, min(64, ((longest + 31) // 32) // 24, -(-10 * 256 // (B * c.kv_heads))))
+        self._ws_attn = torch.empty(max(ops.attention_workspace_bytes(B, c.kv_heads, c.heads // c.kv_heads, self.nsplit, c.head_dim), 256),
+                                    dtype=torch.uint8, device=dev)
+
+    def reorder(self, beam_idx):
+        """slot b continues the sequence that slot beam_idx[b] held (HF `reorder_cache`): the used rows of every layer's cache are gathered"""
+        idx = torch.as_tensor(beam_idx, dtype=torch.int64, device=self.lm.device)
+        if bool((idx.cpu() == torch.arange(self.B)).all()):
+            return
+        n = int(self.len.max().item())
+        for cl in self.cache:
+            cl[:, :n].copy_(cl[:, :n].index_select(0, idx))
+        self.len.copy_(self.len.index_select(0, idx))
 
     def _pick(self, logits, sp, counter=None):
         """next token per sequence on the device (sampling.hip): HF's processor chain of `sp` over the ids each sequence generated so far
@@ -710,10 +741,27 @@ class LlavaQwenForCausalLM:
         inputs_embeds prompts.  `use_cache` is accepted for call compatibility; a KV cache is always used.  Sampling arguments follow
         HF: what the caller passes (even None) wins over the checkpoint's generation_config.json, which wins over HF's defaults
         (`resolve_sampling`); the chain repetition penalty -> temperature -> top-k -> top-p runs in sampling.hip."""
-        if num_beams not in (None, 1):
-            raise NotImplementedError("beam search is not built (the reference runs num_beams=1, inference_streaming_longva_v2.py:73)")
         sp = resolve_sampling(self.generation_config, do_sample, temperature, top_p, top_k, repetition_penalty)
         _, _, _, _, embeds, _ = self.prepare_inputs_embeddings_for_multimodal(inputs, None, None, None, None, image_embeddings, modalities)
+        if num_beams not in (None, 1):
+            # HF `generate(num_beams=N, do_sample=False)` (round 6; beam.py restates the algorithm, this is the model side): the prompt is
+            # prefilled once, its cache rows replicated over N slots of a BatchDecoder; every step feeds one token per beam after gathering the
+            # caches by the beams' origins.  Deterministic beam search only: beam SAMPLING (do_sample with beams) and logits processors on
+            # beams are not built and say so.
+            if sp.temperature > 0:
+                raise NotImplementedError("beam sampling (num_beams > 1 with do_sample / temperature > 0) is not built: use temperature 0 with num_beams > 1")
+            if sp.repetition_penalty != 1.0:
+                raise NotImplementedError("beam search with a repetition penalty is not built")
+            from .beam import beam_search
+            eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])
+            dec = BatchDecoder(self.lm, [embeds[0]], max_new_tokens, replicate=int(num_beams))
+            dec.prepare_steps(max_new_tokens)
+
+            def step(tokens, origin):
+                dec.reorder(origin)
+                return dec.step(tokens.to(device=self.device, dtype=torch.int32))
+            toks, self.last_beam_score = beam_search(dec.logits, step, int(num_beams), max_new_tokens, eos)
+            return torch.tensor([toks], dtype=torch.long, device=self.device)
         self.lm.reset_cache(max_seq=max(self.lm.max_seq, embeds.shape[1] + max_new_tokens))
         logits = self.lm.forward(embeds[0])
         eos = self.eos_token_id if isinstance(self.eos_token_id, (list, tuple, set)) else ([] if self.eos_token_id is None else [self.eos_token_id])

@@ -25,12 +25,14 @@ def _args(m, extra):
         raise
 
 
-def test_num_beams_other_than_one_is_refused_before_anything_is_loaded(capsys):
-    """the reference forwards --num_beams to HF generate (:254); this build has no beam search and says so at parse time
-    (exit code 2, one line on stderr) instead of a NotImplementedError out of the first answer."""
+def test_beam_sampling_is_refused_before_anything_is_loaded_and_beam_search_is_accepted(capsys):
+    """the reference forwards --num_beams to HF generate (:254).  Deterministic beam search is built (streamchat_amd/beam.py:
+    --num_beams N --temperature 0); beam SAMPLING (the reference's default temperature 0.2 with beams) is not, and says so at parse time (exit
+    code 2, one line on stderr) instead of a NotImplementedError out of the first answer."""
     m = _entry()
     assert _args(m, []).num_beams == 1 and _args(m, ["--num_beams", "1"]).num_beams == 1
+    assert _args(m, ["--num_beams", "3", "--temperature", "0"]).num_beams == 3
     with pytest.raises(SystemExit) as e:
         _args(m, ["--num_beams", "3"])
     assert e.value.code == 2
-    assert "beam search is not implemented" in capsys.readouterr().err
+    assert "beam sampling is not implemented" in capsys.readouterr().err
