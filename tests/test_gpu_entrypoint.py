@@ -86,3 +86,23 @@ def test_overlap_with_the_reference_sampling_settings_runs_to_completion(tmp_pat
     E.run_inference(args)
     out = json.load(open(tmp_path / "out.json"))
     assert len(out) == 6 and all(isinstance(r["predict"], str) for r in out)
+
+
+def test_entry_point_runs_beam_search_answers(tmp_path):
+    """--num_beams 2 --temperature 0 through the whole entry point (round 6: HF-semantics beam search, streamchat_amd/beam.py) with the look-ahead on (the default)
+    and off: same answers - the beam path has no prefill hook, the look-ahead then starts when the answer is out."""
+    import inference_streaming_longva_v2 as E
+    import torch
+    outs = []
+    for extra in ([], ["--overlap", "0"]):
+        d = tmp_path / ("a" + str(len(outs)))
+        os.makedirs(d, exist_ok=True)
+        args = E.parse_args(["--video_dir", "none", "--model_name", "none", "--memory_basic_dir", str(d / "mem"), "--save_file", str(d / "out.json"),
+                             "--annotations", "none", "--language", "en", "--conv-mode", "qwen_1_5", "--synthetic", "1", "--synthetic_breakpoints", "2", "--tiny",
+                             "--chunk_size", "4", "--num_clusters", "2", "--interval", "3", "--short_window", "6", "--remember_window", "3", "--max_new_tokens", "10",
+                             "--multi_modal_memory", "--num_beams", "2", "--temperature", "0"] + extra)
+        import numpy as np, random
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        E.run_inference(args)
+        outs.append([r["predict"] for r in json.load(open(d / "out.json"))])
+    assert len(outs[0]) == 2 and outs[0] == outs[1]
