@@ -139,8 +139,9 @@ class Qwen2Model:
         if max_seq is not None:
             self.max_seq = max_seq
         if self.cache is None or self.cache[0].shape[0] < self.max_seq:
-            self.cache = [torch.empty((self.max_seq, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=self.device)
-                          for _ in range(c.layers)]
+            # rows of [K of all KV heads | V of all KV heads]; KV_ROW_PAD extra halves per row (a view: every kernel takes the row stride)
+            w = 2 * c.kv_heads * c.head_dim
+            self.cache = [torch.empty((self.max_seq, w + KV_ROW_PAD), dtype=torch.float16, device=self.device)[:, :w] for _ in range(c.layers)]
         self.cache_len = 0
         self._nsplit_prompt = None
 
@@ -291,6 +292,14 @@ def _lib_pick_bytes(B):
 
 
 _UNSET = object()
+# KV-cache row padding in halves (SC_KV_PAD overrides; 0 = rows 2 * Hkv * Dh halves apart).  A row is [K of the 4 KV heads | V of the 4 KV heads] =
+# 2048 B at Qwen2-7B's widths, so head h's 256-byte piece of consecutive rows sits 2048 B apart: every row of a head falls into the same slot of
+# the memory channels' interleave, and the decode attention's in-kernel timeline showed ONE head's stream ending 2.7 us after the others - its
+# addresses, not its CUs (profiles/r05_run_m_*).  128 B of padding per row (2176 B apart) walks the slots: +1.4 % tokens/s at a 49 k context in
+# the real token loop, interleaved on two boxes (325.2 -> 329.8 and 325.5 -> 330.3; 64 B: +0.2 %, 192 - 512 B: +1.0 - 1.3 %), the prefill unchanged,
+# results bit-identical (profiles/r06_run_k_kv_row_padding.md).  Every kernel takes the row stride, so the cache is a view of the padded rows.
+import os as _os
+KV_ROW_PAD = int(_os.environ.get("SC_KV_PAD", "64"))
 
 # The default CUDA generator of a device has ONE capture state: while a host thread captures a graph (torch.cuda.graph puts the generator into
 # capture mode, whether or not the graph draws from it), a draw or the replay of a sampling graph on ANOTHER host thread fails ("... during
@@ -507,6 +516,7 @@ class BatchDecoder:
         dev = lm.device
         self._rope_tabs = lm.rope_tabs(self.cap)                 # rotary tables cover every position of this batch before a step is captured; the
                                                                  # reference held here keeps them alive if the process-wide cache regrows
+        # (dense rows here: padded rows - KV_ROW_PAD - measured no gain on the batched step, 10.64 / 10.68 against 10.67 / 10.73 ms: 26 streams at 26 bases)
         self.cache = [torch.empty((self.B, self.cap, 2 * c.kv_heads * c.head_dim), dtype=torch.float16, device=dev) for _ in range(c.layers)]
         self.len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self._ws_pick = torch.empty(max(ops.sample_token_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)      # owned: the decode step is graph-captured
