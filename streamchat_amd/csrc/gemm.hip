@@ -541,12 +541,20 @@ __global__ __launch_bounds__(WR * 256, 2) void k_gemm256(const _Float16* __restr
 #ifndef SC_FAT_SNAKE
 #define SC_FAT_SNAKE 1
 #endif
-template <int EPI, bool PERSIST>
+template <int EPI, bool PERSIST, bool RES = false>
 __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ R, int ldr,
                                                      void* __restrict__ Cout, int ldc, int M, int N, int K, int tilesN, int GM, int ntiles,
                                                      const float* __restrict__ tab, int pos0, int lead_cols, float col_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // RES: the launch has a residual operand (R != null) - a template parameter, not a run-time branch: with both sides of the epilogue compiled into
+    // one kernel the live ranges of the residual side count against the 256 VGPRs of the other one (the k|v rotary instantiation carried 280 B of
+    // scratch per lane for a residual branch its launcher can never take; the plain ones 20 - 36 B)
+    // (the column-scale instantiation - CLIP's fused q|k|v projection, 46 launches per step - keeps the never-taken residual side compiled in: without it
+    //  hipcc allocates its epilogue differently and the launch is 0.7 % SLOWER, 5 + 5 interleaved rounds in both orders, profiles/r06_run_m_*; the rotary
+    //  and plain instantiations do not care)
+    constexpr bool HAS_R = RES || EPI == SC_EPI_COLSCALE;
+    static_assert(!RES || EPI == SC_EPI_NONE || EPI == SC_EPI_QUICK_GELU || EPI == SC_EPI_GELU_ERF, "residual: plain / activation epilogues only");
     // virtual block vb -> tile (same XCD-aware grouped order for the one-tile-per-workgroup launch and the persistent walk
     // vb = blockIdx.x, + gridDim.x, ...; gridDim.x is a multiple of 8 there, so a workgroup stays on the XCD slice of its tiles)
     const int tilesM = ntiles / tilesN;
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         int nk_here = nk;
         asm volatile("" : "+s"(nk_here));
         const int fin = (k + 1 >= nk_here) ? 1 : 0;
-        const int relax = (PERSIST && k == 0 && tcount > 0) ? (R && EPI != SC_EPI_SWIGLU ? 2 : 1) : 0;       // stores of the previous tile's epilogue may still be in flight
+        const int relax = (PERSIST && k == 0 && tcount > 0) ? (HAS_R && R ? 2 : 1) : 0;       // stores of the previous tile's epilogue may still be in flight
         // s_nop: the accumulators are zeroed by VALU writes in the loop preheader and the hazard recognizer does not know that the asm
         // below reads them as MFMA SrcC; everything after this statement is in the loop body, so three wait states are guaranteed
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         // ... and the first 16-row tile of the wave's residual block to its C slab (4 rounds of 4 rows x 256 B; the counted wait of the
         // next iteration 0 knows about them, `relax` = 2): its ~2.6 us of HBM latency pass under the K loop instead of at the head of
         // the epilogue.  Slab layout applied at the source: LDS position (row, chunk p) receives chunk p ^ row.
-        if (EPI != SC_EPI_SWIGLU && R) {
+        if (HAS_R && R) {
             const int m0b = __builtin_amdgcn_readfirstlane(tm * BM2 + wr * 128);
             const int rvb = (M - m0b) < 0 ? 0 : ((M - m0b) > 16 ? 16 : (M - m0b));
 #pragma unroll
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
         sstore(7, d);
     } else {
         const __amdgpu_buffer_rsrc_t rs_c = uniform_rsrc(Ch + (size_t)m0 * (size_t)ldc + n0, rv * ldc * 2);
-        const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(R ? R + (size_t)m0 * (size_t)ldr + n0 : W, R ? rv * ldr * 2 : 0);
+        const __amdgpu_buffer_rsrc_t rs_r = uniform_rsrc(HAS_R && R ? R + (size_t)m0 * (size_t)ldr + n0 : W, HAS_R && R ? rv * ldr * 2 : 0);
         // SC_EPI_COLSCALE: the wave's 128 columns are scaled if they lie in [0, lead_cols) (the query third of a fused q|k|v projection
         // carries the softmax scale * log2 e into sc_attention_f16's pre-scaled mode: applied to the fp32 sum, ONE rounding)
         const float cscale = (EPI == SC_EPI_COLSCALE && n0 < lead_cols) ? col_scale : 1.0f;
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(const _Float16* __restrict_
                 if (st + 2 < 16) load_tab(st + 2, ca, sa);
                 rstep(st + 1, cb, sb);
             }
-        } else if (R) {
+        } else if (HAS_R && R) {
             // (the bias values are made opaque on each side of this branch: hipcc otherwise hoists the `acc + bias` adds common to both
             // sides above the branch and parks the sums in AGPRs and scratch)
             // residual rows are requested three row tiles ahead (row tile 0: by DMA at the top of the tile), and before the stores of the step in
@@ -1665,15 +1673,22 @@ int launch_gemm(const void* A, int lda, const void* W, const void* bias, const v
             // persistent walk (one workgroup per CU) once there are more tiles than CUs: the next tile's first iterations are
             // fetched under the epilogue of the current one
             const bool fp = persist && fat != 2 && nt_all > n_cu;
-            static std::atomic<bool> fattr[16][8][2];
-            if (!fattr[dev][EPI][fp]) {
-                (void)hipFuncSetAttribute(fp ? (const void*)k_gemm_fat<EPI, true> : (const void*)k_gemm_fat<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                fattr[dev][EPI][fp] = true;
+            constexpr bool CAN_R = EPI == SC_EPI_NONE || EPI == SC_EPI_QUICK_GELU || EPI == SC_EPI_GELU_ERF;
+            SC_REQUIRE(CAN_R || !R, "sc_gemm_f16: this epilogue takes no residual");
+            static std::atomic<bool> fattr[16][8][2][2];
+            const bool res = CAN_R && R != nullptr;
+            const void* kfn = res ? (fp ? (const void*)k_gemm_fat<EPI, true, CAN_R> : (const void*)k_gemm_fat<EPI, false, CAN_R>)
+                                  : (fp ? (const void*)k_gemm_fat<EPI, true, false> : (const void*)k_gemm_fat<EPI, false, false>);
+            if (!fattr[dev][EPI][fp][res]) {
+                (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                fattr[dev][EPI][fp][res] = true;
             }
-            if (fp) hipLaunchKernelGGL((k_gemm_fat<EPI, true>), dim3(n_cu), dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                                       (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
-            else hipLaunchKernelGGL((k_gemm_fat<EPI, false>), grid2, dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias,
-                                    (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f);
+#define SC_LFAT(P, RS, GRID)                                                                                                              \
+            hipLaunchKernelGGL((k_gemm_fat<EPI, P, RS>), GRID, dim3(256), 163840, s, (const _Float16*)A, lda, (const _Float16*)W, (const _Float16*)bias, \
+                               (const _Float16*)R, ldr, C, ldc, M, N, K, tN, gm_sel, nt_all, (const float*)nullptr, 0, 0, 1.0f)
+            if (res) { if (fp) SC_LFAT(true, CAN_R, dim3(n_cu)); else SC_LFAT(false, CAN_R, grid2); }
+            else { if (fp) SC_LFAT(true, false, dim3(n_cu)); else SC_LFAT(false, false, grid2); }
+#undef SC_LFAT
             SC_CHECK_LAUNCH("sc_gemm_f16");
             return SC_OK;
         }
