@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--decode-tokens", type=int, default=512, help="decode tokens measured AFTER the timed region (reported separately)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU-baseline slice (SURVEY 8(d): 64 = C1's encode)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path with world size 1 (testing)")
+    ap.add_argument("--dp-lloyd", action="store_true", help="N > 1: the merge group's k-means data-parallel over columns (sharded._dp_lloyd; "
+                    "same bits as the owner-rank path, which stays the default until a multi-GPU box has run it); = SC_DP_LLOYD=1")
     ap.add_argument("--preflight", action="store_true",
                     help="check the job instead of running it: visible GPUs, chunk partition, free HBM per rank, one 1-element all-gather and one "
                          "point-to-point round per peer; ONE JSON line, exit code 0 / 3")
@@ -612,6 +614,8 @@ def preflight(a, rank, world, local):
 
 def main():
     a = parse()
+    if a.dp_lloyd:
+        os.environ["SC_DP_LLOYD"] = "1"                   # (read by sharded.ShardedMemory; the argument reaches self-started ranks through sys.argv)
     if a.gpus > 1 and "LOCAL_RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
         sys.exit(relaunch_one_rank_per_gpu(a.gpus))       # not under a launcher (no LOCAL_RANK) and no N-rank job around us: start the ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -802,6 +806,10 @@ def main():
         tr = pipe.last["mem"].traffic
         out["collective"] = dict(kind="gather-to-root (batch_isend_irecv)", fetches_with_traffic=tr["fetches"], bytes_moved_last_step=tr["bytes_moved"],
                                  note="round 4's all-gather of the selected rows moved world x max-rows-per-rank slots to EVERY rank")
+        if pipe.last["mem"].dp_lloyd:
+            out["collective"]["dp_lloyd"] = dict(fits_last_step=tr["dp_lloyd_fits"], bytes_moved_last_step=tr["dp_lloyd_bytes"],
+                                                 what="merge-group k-means data-parallel over columns (sc_kmeans_fit_cols): rows transposed into column slabs "
+                                                      "point to point, two fp64 segment tables all-gathered per Lloyd iteration, centroid slabs to the executor")
     out.update(config=dict(workload=names[config], context_tokens=pipe.last.get("context"), frames_total=n_total, frames_rank0=pipe.n,
                            frames_per_gpu=per_gpu, micro_batch=MICRO_BATCH, parallelism=f"dp{world}" + (" (sharded path)" if sharded else ""),
                            weights="random-init", launcher="self (bare command)" if os.environ.get("SC_BENCH_SELF_LAUNCHED") == "1" else

@@ -59,8 +59,10 @@ enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_WORKSPACE = -2, SC_ERR_LAUNCH = -3, SC
  *      version 6's in the last bits), workspace layout changed (sc_kmeans_workspace_bytes says how much, as always);
  *      + sc_counter_uniform_f32 (the uniform draw of the n-th sampled token as a pure function of (seed, n): batched == one-by-one and
  *      graph == eager under sampling, no generator state on the device)
+ *   8  round 6: + sc_kmeans_fit_cols (sc_kmeans_fit on a column slab of X that holds whole SC-KM2 segments, with a caller-supplied exchange of the
+ *      two fp64 segment tables per iteration: the data-parallel Lloyd of a merge group, bit-identical to the 1-GPU fit at any rank count)
  */
-#define SC_ABI_VERSION 7
+#define SC_ABI_VERSION 8
 
 int sc_abi_version(void);
 const char* sc_last_error(void);
@@ -101,6 +103,28 @@ int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, const float
                   const int32_t* init_idx, const int32_t* reseed_idx, int n_reseed,
                   int max_iter, float tol, float* C, int64_t* labels, float* wsum, int32_t* info,
                   void* ws, size_t ws_bytes, sc_stream_t stream);
+/* v8: the same fit, DATA-PARALLEL OVER COLUMNS (`north_star`: "k-means data-parallel"; reference utiles.py:294-318 on one device).  Under SC-KM2
+ * a distance is 32 contiguous SEGMENTS of 2048-column groups summed in fp64 and then the 32 segment sums in order; updates, reseeds and the
+ * initial rows are per column; the convergence shift has the distance structure.  A rank that holds the columns of whole segments therefore
+ * computes exactly the segment sums the 1-GPU fit computes, and once the two small segment tables are complete on every rank, the arg-min,
+ * ordering and convergence kernels run replicated on identical inputs: labels, wsum, info and the rank's columns of C are bit-identical to
+ * sc_kmeans_fit on the whole matrix, for any number of ranks.
+ *   X            [T, D_local] row-major: columns [seg_first * seg_groups * 2048, ...) of the whole matrix - segments seg_first ..
+ *                seg_first + seg_count - 1; seg_groups = ceil(ceil(D / 2048) / 32) of the WHOLE matrix (groups per segment).  Every slab but the
+ *                matrix's last holds seg_count * seg_groups whole groups; the last one (seg_first + seg_count == 32) holds what is left
+ *   C_local      [K, D_local] fp32 out: this slab's columns of the centroids;  labels / wsum / info: as sc_kmeans_fit, identical on every rank
+ *   seg_dist     [32, T * K] fp64, seg_shift [32, K] fp64: caller-owned device tables.  The library writes this slab's rows
+ *                [seg_first, seg_first + seg_count) and then calls `exchange(ctx, what, stream)` (what 0: seg_dist, 1: seg_shift), which must
+ *                make ALL 32 rows of that table valid on `stream` order (an all-gather of the ranks' row windows; RCCL enqueues it, a host-staged
+ *                transport synchronises the stream) and return 0; max_iter calls of each kind, on every rank, whatever the convergence flag says
+ *   ws           sc_kmeans_workspace_bytes(T, D_local, K)
+ * The call enqueues the whole loop like sc_kmeans_fit; it returns SC_ERR_LAUNCH if an exchange reports failure. */
+typedef int (*sc_kmeans_exchange_fn)(void* ctx, int what, sc_stream_t stream);
+int sc_kmeans_fit_cols(const void* X, int dtype, int T, int64_t D_local, int K, const float* w,
+                       const int32_t* init_idx, const int32_t* reseed_idx, int n_reseed,
+                       int max_iter, float tol, float* C_local, int64_t* labels, float* wsum, int32_t* info,
+                       int64_t seg_groups, int seg_first, int seg_count, double* seg_dist, double* seg_shift,
+                       sc_kmeans_exchange_fn exchange, void* exchange_ctx, void* ws, size_t ws_bytes, sc_stream_t stream);
 /* One assignment step against given centroids (the `kmeans_predict` surface of
  * kmeans_pytorch/__init__.py:130 and torch_kmeans KMeans.predict): labels [T] int64,
  * dist2 [T, K] fp64 squared Euclidean distances (may be NULL). */

@@ -15,8 +15,12 @@ class StreamChatHipError(RuntimeError):
     pass
 
 
+# sc_kmeans_exchange_fn: int (*)(void* ctx, int what, sc_stream_t stream)
+KMEANS_EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
+
+
 # name -> (restype, [argtypes])   — keep in sync with include/streamchat_hip.h
-ABI_VERSION = 7            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
+ABI_VERSION = 8            # include/streamchat_hip.h SC_ABI_VERSION this binding was written against
 SIGNATURES = {
     "sc_abi_version": (c_int, []),
     "sc_last_error": (c_char_p, []),
@@ -27,6 +31,9 @@ SIGNATURES = {
     "sc_kmeans_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "sc_kmeans_fit": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sc_kmeans_fit_cols": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, KMEANS_EXCHANGE_FN, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
     "sc_kmeans_assign": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sc_kmeans_update": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -234,15 +234,18 @@ __global__ __launch_bounds__(WPB * 64) void km_assign(const void* __restrict__ X
     }
 }
 
-// level-1 fp64 reduce: seg[s][item] = sum_{g in segment s, ascending} gpart[g][item]
+// level-1 fp64 reduce: seg[s][item] = sum_{g in segment s, ascending} gpart[g][item].  `seglen` groups per segment; the matrix at hand holds
+// segments [seg_first, seg_first + seg_count) of the 32 (the whole matrix: 0, 32; a column slab of sc_kmeans_fit_cols: the segments it owns -
+// its local group 0 is the first group of segment seg_first, the other rows of `seg` are left to the exchange)
 __global__ void km_reduce(const double* __restrict__ partial, const KmState* __restrict__ st, double* __restrict__ seg,
-                          size_t I, int64_t nchunks, int check_done) {
+                          size_t I, int64_t nchunks, int check_done, int64_t seglen, int seg_first, int seg_count) {
     if (check_done && st->done) return;
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= I) return;
     const int s = blockIdx.y;
-    const int64_t seglen = (nchunks + NSEG - 1) / NSEG;
-    int64_t lo = (int64_t)s * seglen, hi = lo + seglen;
+    if (s < seg_first || s >= seg_first + seg_count) return;
+    int64_t lo = (int64_t)(s - seg_first) * seglen, hi = lo + seglen;
+    if (lo > nchunks) lo = nchunks;
     if (hi > nchunks) hi = nchunks;
     double a = 0.0;
     int64_t c = lo;
@@ -830,6 +833,54 @@ __global__ __launch_bounds__(256) void km_decide(const double* __restrict__ dpar
     }
 }
 
+// ---- column-sharded fit (sc_kmeans_fit_cols): the two halves of km_decide with the exchange of the segment sums between them ----
+// single block: sseg[s][k] = sum_{g in segment s of this slab, ascending} dgpart[g][k] for the slab's segments [seg_first, seg_first + seg_count)
+__global__ __launch_bounds__(256) void km_shift_segs(const double* __restrict__ dpart, const KmState* __restrict__ st, double* __restrict__ sseg, int K,
+                                                     int64_t nchunks, int64_t seglen, int seg_first, int seg_count) {
+    if (st->done) return;
+    for (int p = threadIdx.x; p < seg_count * K; p += blockDim.x) {
+        const int sl = p / K, k = p % K;
+        int64_t lo = (int64_t)sl * seglen, hi = lo + seglen;
+        if (lo > nchunks) lo = nchunks;
+        if (hi > nchunks) hi = nchunks;
+        double a = 0.0;
+        int64_t c = lo;
+        for (; c + 8 <= hi; c += 8) {                 // (the order of km_shift_totals)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dpart[(size_t)(c + u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; c < hi; ++c) a += dpart[(size_t)c * K + k];
+        sseg[(size_t)(seg_first + sl) * K + k] = a;
+    }
+}
+// single block: km_decide from all 32 segment rows (identical on every rank after the exchange)
+__global__ __launch_bounds__(64) void km_decide_segs(const double* __restrict__ sseg, KmState* __restrict__ st, int K, int iter, int max_iter, float tol,
+                                                     int n_reseed) {
+    if (st->done) return;
+    if (threadIdx.x == 0) {
+        double diff = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (int s = 0; s < NSEG; ++s) t += sseg[(size_t)s * K + k];
+            diff += sqrt(t);
+        }
+        if (st->n_empty > 0) {
+            if (st->reseed_pos + st->n_empty > n_reseed) st->status = 1;
+            st->reseed_pos += st->n_empty;
+        }
+        if (diff < (double)tol) {
+            st->done = 1;
+            st->exit_iter = iter;
+        } else {
+            st->cur ^= 1;
+            if (iter == max_iter - 1) { st->done = 1; st->exit_iter = iter; }
+        }
+    }
+}
+
 // single block: shift2[k] = ||C_k - C'_k||^2 (fp64) for the caller of sc_kmeans_update; W -> wsum
 __global__ __launch_bounds__(256) void km_shift_out(const double* __restrict__ dpart, const float* __restrict__ W, double* __restrict__ shift2,
                                                     float* __restrict__ wsum, int K, int64_t nchunks) {
@@ -1027,7 +1078,7 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     for (int it = 0; it < max_iter; ++it) {
         if (!fused) launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
         else if (it == 0) km2_launch<2>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
-        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 1);
+        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 1, (ng + NSEG - 1) / NSEG, 0, NSEG);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
         hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
         // (the last iteration has no next assign: its update alone is a load-latency-bound pass for km2_pass - 0.49 ms against 0.42 for km_update)
@@ -1037,6 +1088,44 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
     }
     hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
     SC_CHECK_LAUNCH("sc_kmeans_fit");
+    return SC_OK;
+}
+
+// The Lloyd loop of fit_impl on a COLUMN SLAB of X that holds whole segments of the SC-KM2 distance structure: what leaves the slab per
+// iteration are its rows of the two segment tables (distances [32][T K], shifts [32][K], fp64); `exchange` completes both tables on every
+// rank, after which arg-min, ordering and the convergence decision are the replicated kernels of the 1-GPU fit on identical inputs.
+template <typename Tag>
+int fit_cols_impl(const void* X, int T, int64_t D, int K, const float* wts, const int32_t* init_idx, const int32_t* reseed_idx,
+                  int n_reseed, int max_iter, float tol, float* C, int64_t* labels, float* wsum, int32_t* info, int64_t seglen, int seg_first,
+                  int seg_count, double* seg_dist, double* seg_shift, sc_kmeans_exchange_fn exchange, void* xctx, void* ws, hipStream_t s) {
+    const KmWs w = carve(ws, T, D, K);
+    const int64_t nch = (D + CH - 1) / CH, ng = (D + GW - 1) / GW;
+    const size_t I = (size_t)T * K;
+    const bool vec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    {
+        const dim3 igrid((unsigned)((D + 2047) / 2048), (unsigned)K);
+        if (vec) hipLaunchKernelGGL((km_init<Tag, true>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+        else hipLaunchKernelGGL((km_init<Tag, false>), igrid, dim3(256), 0, s, X, init_idx, w.Ca, w.st, T, D, K);
+    }
+    const dim3 rgrid((unsigned)((I + 255) / 256), NSEG);
+    const bool fused = km2_eligible<Tag>(X, T, D, K);
+    for (int it = 0; it < max_iter; ++it) {
+        if (!fused) launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
+        else if (it == 0) km2_launch<2>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, seg_dist, I, ng, 1, seglen, seg_first, seg_count);
+        SC_CHECK_LAUNCH("sc_kmeans_fit_cols");
+        if (exchange(xctx, 0, (sc_stream_t)s) != 0) return sc_fail(SC_ERR_LAUNCH, "sc_kmeans_fit_cols: the exchange of the distance segments failed (iteration %d)", it);
+        hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, seg_dist, w.st, w.labels32, (double*)nullptr, T, K, 1);
+        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
+        if (!fused || it + 1 == max_iter) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
+        else km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
+        hipLaunchKernelGGL(km_shift_segs, dim3(1), dim3(256), 0, s, w.dgpart, w.st, seg_shift, K, ng, seglen, seg_first, seg_count);
+        SC_CHECK_LAUNCH("sc_kmeans_fit_cols");
+        if (exchange(xctx, 1, (sc_stream_t)s) != 0) return sc_fail(SC_ERR_LAUNCH, "sc_kmeans_fit_cols: the exchange of the shift segments failed (iteration %d)", it);
+        hipLaunchKernelGGL(km_decide_segs, dim3(1), dim3(64), 0, s, seg_shift, w.st, K, it, max_iter, tol, n_reseed);
+    }
+    hipLaunchKernelGGL(km_finalize, dim3(1024), dim3(256), 0, s, w.Ca, w.Cb, w.st, w.labels32, w.W, C, labels, wsum, info, T, D, K);
+    SC_CHECK_LAUNCH("sc_kmeans_fit_cols");
     return SC_OK;
 }
 
@@ -1050,7 +1139,7 @@ int assign_impl(const void* X, int T, int64_t D, int K, const float* C, int64_t*
     w.Ca = const_cast<float*>(C);   // read-only use: state.cur == 0 selects Ca
     if (km2_eligible<Tag>(X, T, D, K) && (reinterpret_cast<uintptr_t>(C) & 31) == 0) km2_launch<2>(X, w.Ca, w.Cb, w, nullptr, nullptr, 0, T, D, K, s);
     else launch_assign<Tag>(vec, X, w, T, D, K, nch, s);
-    hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 0);
+    hipLaunchKernelGGL(km_reduce, dim3((unsigned)((I + 255) / 256), NSEG), dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 0, (ng + NSEG - 1) / NSEG, 0, NSEG);
     hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, dist2, T, K, 0);
     hipLaunchKernelGGL(km_labels_out, dim3((T + 255) / 256), dim3(256), 0, s, w.labels32, labels, T);
     SC_CHECK_LAUNCH("sc_kmeans_assign");
@@ -1107,6 +1196,40 @@ extern "C" int sc_kmeans_fit(const void* X, int dtype, int T, int64_t D, int K, 
         case SC_F32: return fit_impl<ScF32>(X, T, D, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C, labels, wsum, info, ws, s);
     }
     return sc_fail(SC_ERR_ARG, "sc_kmeans_fit: unknown dtype %d", dtype);
+}
+
+extern "C" int sc_kmeans_fit_cols(const void* X, int dtype, int T, int64_t D_local, int K, const float* w, const int32_t* init_idx,
+                                  const int32_t* reseed_idx, int n_reseed, int max_iter, float tol, float* C_local, int64_t* labels,
+                                  float* wsum, int32_t* info, int64_t seg_groups, int seg_first, int seg_count, double* seg_dist,
+                                  double* seg_shift, sc_kmeans_exchange_fn exchange, void* exchange_ctx, void* ws, size_t ws_bytes,
+                                  sc_stream_t stream) {
+    SC_REQUIRE(X && init_idx && C_local && labels && wsum && info && ws && seg_dist && seg_shift && exchange, "sc_kmeans_fit_cols: null pointer argument");
+    SC_REQUIRE(T > 0 && D_local > 0 && K > 0 && max_iter > 0, "sc_kmeans_fit_cols: T, D_local, K, max_iter must be positive");
+    SC_REQUIRE(n_reseed >= 0 && (n_reseed == 0 || reseed_idx), "sc_kmeans_fit_cols: n_reseed > 0 needs reseed_idx");
+    SC_REQUIRE(seg_groups > 0 && seg_first >= 0 && seg_count > 0 && seg_first + seg_count <= NSEG, "sc_kmeans_fit_cols: bad segment window");
+    {
+        // the slab holds whole segments: all of its groups but the last are whole (only the matrix's last group may be short), and they
+        // fill segments seg_first .. seg_first + seg_count - 1 in order (the last one possibly short or empty: the matrix's tail)
+        const int64_t ngl = (D_local + GW - 1) / GW;
+        SC_REQUIRE(ngl <= (int64_t)seg_count * seg_groups, "sc_kmeans_fit_cols: %lld groups do not fit %d segments of %lld", (long long)ngl, seg_count, (long long)seg_groups);
+        SC_REQUIRE(seg_first + seg_count == NSEG || ngl == (int64_t)seg_count * seg_groups,
+                   "sc_kmeans_fit_cols: a slab that is not the matrix's last one holds seg_count * seg_groups whole groups");
+        SC_REQUIRE(seg_first + seg_count == NSEG || D_local % GW == 0, "sc_kmeans_fit_cols: only the matrix's last slab may end in a partial group");
+    }
+    if (ws_bytes < sc_kmeans_workspace_bytes(T, D_local, K))
+        return sc_fail(SC_ERR_WORKSPACE, "sc_kmeans_fit_cols: workspace %zu < required %zu", ws_bytes, sc_kmeans_workspace_bytes(T, D_local, K));
+    SC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0 && (reinterpret_cast<uintptr_t>(seg_dist) & 7) == 0 && (reinterpret_cast<uintptr_t>(seg_shift) & 7) == 0,
+               "sc_kmeans_fit_cols: workspace must be 256-byte aligned, the segment tables 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+#define SC_FC(Tag) return fit_cols_impl<Tag>(X, T, D_local, K, w, init_idx, reseed_idx, n_reseed, max_iter, tol, C_local, labels, wsum, info, seg_groups, seg_first, \
+                                            seg_count, seg_dist, seg_shift, exchange, exchange_ctx, ws, s)
+        case SC_F16: SC_FC(ScF16);
+        case SC_BF16: SC_FC(ScBF16);
+        case SC_F32: SC_FC(ScF32);
+#undef SC_FC
+    }
+    return sc_fail(SC_ERR_ARG, "sc_kmeans_fit_cols: unknown dtype %d", dtype);
 }
 
 extern "C" int sc_kmeans_update(const void* X, int dtype, int T, int64_t D, int K, const float* w, const int64_t* labels, const float* C_old,

@@ -129,6 +129,20 @@ def all_gather_rows(ctx, recv, send):
         dist.all_gather_into_tensor(recv, send)
 
 
+def all_gather_row_windows(ctx, table, windows):
+    """table [rows, n] (the same shape on every rank): rank q owns rows windows[q] = (first, count); afterwards every rank holds every
+    window.  One all_gather_into_tensor of equal slots (the widest window; 32 fp64 rows x T K of the data-parallel k-means: 512 KB)."""
+    first, count = windows[ctx.rank]
+    cmax = max(c for _, c in windows)
+    send = table.new_zeros((cmax,) + tuple(table.shape[1:]))
+    send[:count].copy_(table[first:first + count])
+    recv = table.new_empty((ctx.world * cmax,) + tuple(table.shape[1:]))
+    all_gather_rows(ctx, recv, send)
+    for q, (f, c) in enumerate(windows):
+        if q != ctx.rank:
+            table[f:f + c].copy_(recv[q * cmax:q * cmax + c])
+
+
 def broadcast_tensor(ctx, t, src=0):
     if _staged(ctx, t):
         h = t.cpu()

@@ -134,6 +134,73 @@ def kmeans_fit(X: torch.Tensor, K: int, init_idx, reseed_idx=None, weights=None,
     return C, labels, wsum, info
 
 
+KM_GROUP, KM_SEGMENTS = 2048, 32          # SC-KM2 constants (csrc/kmeans.hip GW / NSEG): columns per fp64 group, segments per distance
+
+
+def kmeans_column_slabs(D: int, world: int):
+    """How sc_kmeans_fit_cols deals the D columns of a matrix to `world` ranks: whole SC-KM2 segments, the non-empty ones as even as they go
+    (a matrix of fewer than 32 x seg_groups groups leaves its last segments empty: they go to the last rank, which owns the matrix's tail).
+    Returns (seg_groups, [(seg_first, seg_count, col_lo, col_hi)] per rank), or None when there are fewer non-empty segments than ranks
+    (few columns: the caller clusters on one rank instead)."""
+    ng = (D + KM_GROUP - 1) // KM_GROUP
+    seg_groups = (ng + KM_SEGMENTS - 1) // KM_SEGMENTS
+    live = (ng + seg_groups - 1) // seg_groups                 # segments that hold at least one group
+    if live < world:
+        return None
+    out = []
+    for r in range(world):
+        s0, s1 = live * r // world, (live * (r + 1) // world if r + 1 < world else KM_SEGMENTS)
+        out.append((s0, s1 - s0, min(D, s0 * seg_groups * KM_GROUP), min(D, s1 * seg_groups * KM_GROUP)))
+    return seg_groups, out
+
+
+def kmeans_fit_cols(X: torch.Tensor, K: int, init_idx, reseed_idx, seg_groups: int, seg_first: int, seg_count: int, exchange,
+                    weights=None, max_iter: int = 10, tol: float = 1e-4):
+    """The data-parallel Lloyd (sc_kmeans_fit_cols): X [T, D_local] is this rank's column slab (`kmeans_column_slabs`), `exchange(what, table)`
+    completes the [32, n] fp64 segment table `table` on every rank from the row windows the ranks own (what 0: distances, 1: shifts) - on the
+    current stream, or after synchronising it.  Returns (C_local [K, D_local] fp32, labels, wsum, info): everything but C_local identical
+    on every rank and bit-identical to kmeans_fit on the whole matrix."""
+    _require_cuda(X)
+    lib = _lib.load()
+    if X.dim() != 2:
+        raise StreamChatHipError("kmeans_fit_cols: X must be [T, D_local]")
+    X = X.contiguous()
+    T, D = X.shape
+    dev = X.device
+    init = torch.as_tensor(init_idx, dtype=torch.int32).to(dev).contiguous()
+    if init.numel() != K:
+        raise StreamChatHipError("kmeans_fit_cols: init_idx must have K entries")
+    rs = None if reseed_idx is None else torch.as_tensor(reseed_idx, dtype=torch.int32).to(dev).contiguous()
+    w = None if weights is None else weights.to(device=dev, dtype=torch.float32).contiguous()
+    C = torch.empty((K, D), dtype=torch.float32, device=dev)
+    labels = torch.empty(T, dtype=torch.int64, device=dev)
+    wsum = torch.empty(K, dtype=torch.float32, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    tables = (torch.zeros((KM_SEGMENTS, T * K), dtype=torch.float64, device=dev), torch.zeros((KM_SEGMENTS, K), dtype=torch.float64, device=dev))
+    failure = []
+
+    def _cb(_ctx, what, _stream):
+        try:
+            exchange(int(what), tables[int(what)])
+            return 0
+        except BaseException as e:          # an exception must not unwind through the C frames: report it through the return code
+            failure.append(e)
+            return 1
+
+    cb = _lib.KMEANS_EXCHANGE_FN(_cb)
+    ws = _workspace(lib.sc_kmeans_workspace_bytes(T, D, K), dev)
+    with torch.cuda.device(dev):
+        rc = lib.sc_kmeans_fit_cols(ptr(X), _code(X), T, c_int64(D), K, ptr(w), ptr(init), ptr(rs), 0 if rs is None else rs.numel(),
+                                    max_iter, c_float(tol), ptr(C), ptr(labels), ptr(wsum), ptr(info), c_int64(seg_groups), seg_first, seg_count,
+                                    ptr(tables[0]), ptr(tables[1]), cb, None, ptr(ws), c_size_t(ws.numel()), stream_ptr(dev))
+    if failure:
+        raise failure[0]
+    check(rc, "sc_kmeans_fit_cols")
+    for t in tables:
+        t.record_stream(torch.cuda.current_stream(dev))
+    return C, labels, wsum, info
+
+
 def kmeans_assign(X: torch.Tensor, C: torch.Tensor, return_dist2: bool = False):
     """labels [T] int64 (and optionally dist2 [T, K] fp64) of rows X against fp32 centroids C."""
     _require_cuda(X, C)

@@ -19,13 +19,15 @@ Frame ranges are never exchanged: they follow from `partition_chunks`.  With wor
 
 The retrieved-frame indices, tree shape and texts therefore do not depend on the number of GPUs
 (tests/test_sharded_gloo.py: world 2 and 4 == the single-stream `updating_memory_buffer` on the same stream)."""
+import os
 import random
 
 import numpy as np
 import torch
 
+from . import ops
 from . import utiles as U
-from .dist import all_gather_rows, broadcast_object, broadcast_tensor, exchange, gather_objects, partition_chunks
+from .dist import all_gather_row_windows, all_gather_rows, broadcast_object, broadcast_tensor, exchange, gather_objects, partition_chunks
 
 BANK, MERGE = 0, 1          # store key kinds: ("bank", segment) frame features / ("merge", node id) k-means centroids
 
@@ -57,8 +59,13 @@ class Ref:
 
 
 class ShardedMemory:
-    def __init__(self, ctx, chunk_size=30, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5, always_collective=False):
+    def __init__(self, ctx, chunk_size=30, num_clusters=5, interval=10, short_window=20, remember_window=5, tau=5, always_collective=False,
+                 dp_lloyd=None):
         self.ctx = ctx
+        # dp_lloyd: run the merge group's k-means DATA-PARALLEL over columns (`_dp_lloyd` below) instead of shipping the group's rows to
+        # one rank.  Same labels and centroids, bit for bit (sc_kmeans_fit_cols).  Default: SC_DP_LLOYD=1 switches it on - off until the
+        # transport has been seen on a multi-GPU box (the owner-rank path is the one the full-size 8-process jobs have run since round 4)
+        self.dp_lloyd = (os.environ.get("SC_DP_LLOYD", "0") == "1") if dp_lloyd is None else bool(dp_lloyd)
         # always_collective: take the collective code paths even where a shortcut exists (world size 1, rows already on the consumer) —
         # lets a single-rank RCCL process group exercise exactly the calls an N-rank run makes (tests/test_gpu_sharded.py)
         self.always_collective = always_collective
@@ -70,7 +77,7 @@ class ShardedMemory:
         self.next_node = 0
         self.row_shape = None       # (P, D), dtype, device of a feature row
         self._send = self._recv = None
-        self.traffic = dict(fetches=0, bytes_moved=0)        # row bytes that crossed ranks in fetch() (computed from the Refs: the same number on every rank)
+        self.traffic = dict(fetches=0, bytes_moved=0, dp_lloyd_fits=0, dp_lloyd_bytes=0)   # row bytes that crossed ranks in fetch() / _dp_lloyd() (computed from the Refs: the same number on every rank)
         self.kmeans_max_iter = 10   # weighted_kmeans_feature's default (utiles.py:291): fixes how many reseed rows a merge draws
 
     # ---------------------------------------------------------------------------------------------
@@ -140,13 +147,20 @@ class ShardedMemory:
                 # draw taken only there would let the ranks' states drift apart); only the executor clusters
                 init_idx = torch.randperm(combined.rows)[:self.num_clusters]
                 reseed_idx = [random.randint(0, combined.rows - 1) for _ in range(self.kmeans_max_iter * self.num_clusters)]
-                X = self.fetch([combined], dst=executor, mode="p2p")
                 node_id = self.next_node
                 self.next_node += 1
-                if ctx.rank == executor:
-                    new_centroids, _ = U.weighted_kmeans_feature(X, self.num_clusters, init_idx=init_idx, reseed_idx=reseed_idx,
-                                                                  max_iter=self.kmeans_max_iter)
-                    self.store[(MERGE, node_id)] = new_centroids
+                (P, D), _, _ = self.row_shape
+                slabs = ops.kmeans_column_slabs(P * D, ctx.world) if (self.dp_lloyd and (ctx.world > 1 or self.always_collective)) else None
+                if slabs is not None:
+                    new_centroids = self._dp_lloyd(combined, executor, init_idx, reseed_idx, slabs)
+                    if ctx.rank == executor:
+                        self.store[(MERGE, node_id)] = new_centroids
+                else:
+                    X = self.fetch([combined], dst=executor, mode="p2p")
+                    if ctx.rank == executor:
+                        new_centroids, _ = U.weighted_kmeans_feature(X, self.num_clusters, init_idx=init_idx, reseed_idx=reseed_idx,
+                                                                      max_iter=self.kmeans_max_iter)
+                        self.store[(MERGE, node_id)] = new_centroids
                 new_ref = Ref([(executor, MERGE, node_id, 0, self.num_clusters)])
             else:
                 new_ref = combined
@@ -161,6 +175,61 @@ class ShardedMemory:
         return nodes, short
 
     # ---------------------------------------------------------------------------------------------
+    def _dp_lloyd(self, combined, executor, init_idx, reseed_idx, slabs):
+        """The merge group's k-means data-parallel over COLUMNS (`north_star`: "k-means data-parallel"; reference utiles.py:294-318 on one
+        device).  Rank q takes the columns of whole SC-KM2 segments (`ops.kmeans_column_slabs`); three steps:
+          1. transpose: every owner of rows of the group sends rank q the columns of q's slab (one batch of point-to-point pieces - the
+             bytes of the gather-to-executor, but spread over all links instead of into one rank's);
+          2. `ops.kmeans_fit_cols` on the [T, D_q] slab: per iteration the ranks exchange their rows of two fp64 segment tables
+             (all-gather, 32 x T K and 32 x K values); arg-min / ordering / convergence run replicated on identical inputs;
+          3. the K centroid rows (cast to the feature dtype per slab, as the 1-GPU path casts the whole rows) go to the executor.
+        Returns the [K, P, D] centroids on the executor (None elsewhere) - the bits `weighted_kmeans_feature` returns on one GPU."""
+        ctx, K = self.ctx, self.num_clusters
+        (P, D), dtype, dev = self.row_shape
+        seg_groups, cols = slabs
+        T = combined.rows
+        s0, cnt, lo, hi = cols[ctx.rank]
+        esz = torch.empty((), dtype=dtype).element_size()
+        X = torch.empty((T, hi - lo), dtype=dtype, device=dev)
+        sends, recvs, off, moved = [], [], 0, 0
+        for p in combined.pieces:
+            n = p[4] - p[3]
+            if p[0] == ctx.rank:
+                rows = self._local(p).reshape(n, P * D)
+                X[off:off + n].copy_(rows[:, lo:hi])
+                sends += [(rows[:, cols[q][2]:cols[q][3]], q) for q in range(ctx.world) if q != ctx.rank]       # (exchange() makes them contiguous)
+            else:
+                recvs.append((X[off:off + n], p[0]))
+            moved += n * (P * D - (cols[p[0]][3] - cols[p[0]][2])) * esz
+            off += n
+        exchange(ctx, sends, recvs)
+        windows = [(c[0], c[1]) for c in cols]
+        C, _, _, _ = ops.kmeans_fit_cols(X, K, init_idx, reseed_idx, seg_groups, s0, cnt,
+                                         lambda what, table: all_gather_row_windows(ctx, table, windows),
+                                         weights=torch.ones(T, dtype=dtype, device=dev), max_iter=self.kmeans_max_iter, tol=1e-4)
+        del X
+        mine = C.to(dtype)
+        sends, recvs, out, tmp = [], [], None, {}
+        if ctx.rank == executor:
+            out = torch.empty((K, P * D), dtype=dtype, device=dev)
+            out[:, lo:hi].copy_(mine)
+            for q in range(ctx.world):
+                if q != executor:
+                    tmp[q] = torch.empty((K, cols[q][3] - cols[q][2]), dtype=dtype, device=dev)
+                    recvs.append((tmp[q], q))
+        else:
+            sends.append((mine, executor))
+        exchange(ctx, sends, recvs)
+        self.traffic["dp_lloyd_fits"] += 1
+        # bytes received, summed over the ranks: the transposed rows, the centroid slabs, max_iter all-gathers of the two segment tables
+        self.traffic["dp_lloyd_bytes"] += moved + K * (P * D - (cols[executor][3] - cols[executor][2])) * esz \
+            + self.kmeans_max_iter * (ctx.world - 1) * ops.KM_SEGMENTS * (T * K + K) * 8
+        if ctx.rank != executor:
+            return None
+        for q, t in tmp.items():
+            out[:, cols[q][2]:cols[q][3]].copy_(t)
+        return out.view(K, P, D)
+
     def _local(self, piece):
         _, kind, i, lo, hi = piece
         return self.store[(kind, i)][lo:hi]

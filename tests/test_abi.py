@@ -26,8 +26,8 @@ def test_binding_covers_header(hip_lib):
 
 
 def test_abi_version_and_error_text(hip_lib):
-    assert hip_lib.sc_abi_version() == 7
-    assert b"abi=7" in hip_lib.sc_build_info() and b"attention=" in hip_lib.sc_build_info()
+    assert hip_lib.sc_abi_version() == 8
+    assert b"abi=8" in hip_lib.sc_build_info() and b"attention=" in hip_lib.sc_build_info()
     # argument validation happens before any device work, so it is callable without a GPU
     rc = hip_lib.sc_kmeans_fit(None, 0, 1, 8, 1, None, None, None, 0, 1, 1e-4, None, None, None, None, None, 0, None)
     assert rc == -1

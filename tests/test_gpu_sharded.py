@@ -201,6 +201,22 @@ def test_processes_retrieve_and_prefill_like_one(nproc, launcher):
     assert many["dist_warm_up"]["all_gather"] and many["dist_warm_up"]["p2p_peers"] == nproc - 1 and many["dist_warm_up"]["timeout_s"] == 120.0
 
 
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_dp_lloyd_processes_retrieve_and_prefill_like_one(nproc):
+    """`bench.py --gpus N --dp-lloyd`: the merge group's k-means DATA-PARALLEL over columns (sharded._dp_lloyd -> sc_kmeans_fit_cols) in a real
+    multi-process job - N processes on this box's one GPU, gloo with host staging: the 400 rows of the merge group are transposed into column
+    slabs of whole SC-KM2 segments (16 + 16 at N = 2, 10 + 11 + 11 at N = 3), every Lloyd iteration all-gathers the ranks' rows of the two fp64
+    segment tables, the centroid slabs go to the executor.  The selected frames, the path text, the context and the first generated token
+    must equal the 1-process run - the merged node's centroids are retrieved rows of this stream - and the record must show the fit."""
+    one = _c4_small_one_process()
+    many = _bench_json(C4_SMALL + ["--gpus", str(nproc), "--dp-lloyd"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=nproc, launcher="bare")
+    assert many["n_gpus"] == nproc
+    for k in ("retrieval_crc32", "first_token", "context_tokens"):
+        assert one["config"][k] == many["config"][k], (k, one["config"][k], many["config"][k])
+    dp = many["collective"]["dp_lloyd"]
+    assert dp["fits_last_step"] >= 1 and dp["bytes_moved_last_step"] > 400 * 576 * 3584 * 2 * (nproc - 1) // nproc
+
+
 def _full_size_pair(cfg_args, tag):
     """the SAME full-size job as ONE process and as EIGHT processes (bare command: bench.py starts its ranks; all on device 0, gloo with host
     staging); both JSON lines are left under gpurun_out/ when that directory exists (copied to profiles/ by hand)"""

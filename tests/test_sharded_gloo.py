@@ -27,6 +27,7 @@ def _free_port():
 
 
 DUPLICATES = False                       # scenario switch (set per worker): frames that are exact copies -> empty clusters -> reseeds
+DP_LLOYD = False                         # scenario switch (set per worker): ShardedMemory(dp_lloyd=True) - the merge k-means data-parallel over columns
 
 
 def _segment(seg, n):
@@ -93,8 +94,33 @@ def _patch_providers():
     def sim_topk(q, docs, k=1, metric="cos"):
         idx, sc = oracle.topk(q.numpy(), docs.numpy(), k, metric)
         return torch.from_numpy(idx), torch.from_numpy(sc)
+    def kmeans_fit_cols(X, K, init_idx, reseed_idx, seg_groups, seg_first, seg_count, exchange, weights=None, max_iter=10, tol=1e-4):
+        """CPU stand-in for the column-sharded fit: (1) drives the caller's exchange once per table with recognisable rows and checks that every
+        rank's window arrived; (2) rebuilds the whole matrix from the ranks' slabs and returns this rank's columns of the ORACLE's centroids."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        sg, cols = ops.kmeans_column_slabs(P_ * D_, world)
+        assert (sg, cols[rank][0], cols[rank][1], cols[rank][3] - cols[rank][2]) == (seg_groups, seg_first, seg_count, X.shape[1])
+        T = X.shape[0]
+        for what, width in ((0, T * K), (1, K)):
+            table = torch.zeros(ops.KM_SEGMENTS, width, dtype=torch.float64)
+            table[seg_first:seg_first + seg_count] = 1000.0 * (rank + 1) + torch.arange(seg_first, seg_first + seg_count, dtype=torch.float64).view(-1, 1)
+            exchange(what, table)
+            for q, (s0, c, _, _) in enumerate(cols):
+                want = 1000.0 * (q + 1) + torch.arange(s0, s0 + c, dtype=torch.float64).view(-1, 1)
+                assert torch.equal(table[s0:s0 + c], want.expand(c, width)), f"segment rows of rank {q} did not arrive on rank {rank}"
+        parts = [None] * world
+        dist.all_gather_object(parts, X.numpy())
+        full = np.concatenate(parts, axis=1)
+        r = oracle.kmeans_fit(full, K, np.asarray(init_idx, np.int32), np.asarray(reseed_idx, np.int32), max_iter=max_iter, trace=True)
+        RESEEDS.append(int(sum(len(set(t.tolist())) < K for t in r["trace"])))
+        lo, hi = cols[rank][2], cols[rank][3]
+        return torch.from_numpy(np.ascontiguousarray(r["centroids"][:, lo:hi])), torch.from_numpy(r["labels"]), None, None
     U.weighted_kmeans_feature = kmeans_feature
     ops.sim_topk = sim_topk
+    ops.kmeans_fit_cols = kmeans_fit_cols
+    if DP_LLOYD:
+        ops.KM_GROUP = 1                 # one column per "group": the 24-column test rows split into 24 non-empty segments
 
 
 def _describe(nodes):
@@ -127,7 +153,7 @@ def _sharded(ctx):
     torch.manual_seed(7)
     random.seed(5)
     rng = np.random.RandomState(11)
-    mem = SH.ShardedMemory(ctx, **MEM)
+    mem = SH.ShardedMemory(ctx, dp_lloyd=DP_LLOYD, **MEM)
     out = []
     for seg, n in enumerate(SEGMENTS):
         a, b = mem.partition(n)[ctx.rank]
@@ -152,13 +178,15 @@ def _sharded(ctx):
             keep = None if x is None else x.clone()
             mem.fetch([leafs[1]], dst=0, mode="allgather")
             assert x is None or torch.equal(x, keep), "an earlier fetch result was overwritten by the next fetch"
+    if DP_LLOYD and ctx.world > 1:
+        assert mem.traffic["dp_lloyd_fits"] > 0, "no merge took the data-parallel path"
     return out
 
 
-def _worker(rank, world, port, q, duplicates=False):
+def _worker(rank, world, port, q, duplicates=False, dp_lloyd=False):
     try:
-        global DUPLICATES
-        DUPLICATES = duplicates
+        global DUPLICATES, DP_LLOYD
+        DUPLICATES, DP_LLOYD = duplicates, dp_lloyd
         os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         from streamchat_amd import dist as D
         _patch_providers()
@@ -191,11 +219,11 @@ def _worker(rank, world, port, q, duplicates=False):
         raise
 
 
-def _run_world(world, duplicates=False):
+def _run_world(world, duplicates=False, dp_lloyd=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, duplicates)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, duplicates, dp_lloyd)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted(q.get(timeout=300) for _ in ps)
     [p.join(timeout=60) for p in ps]
@@ -236,12 +264,25 @@ def test_sharded_empty_cluster_reseeds_stay_in_lockstep_with_single_stream():
     _run_world(3, duplicates=True)
 
 
+@pytest.mark.timeout(900)
+def test_sharded_dp_lloyd_equals_single_stream_world2_3_and_8():
+    """`ShardedMemory(dp_lloyd=True)`: the merge k-means data-parallel over COLUMNS (sharded._dp_lloyd).  Here the control flow on CPU - the
+    transposing exchange of the group's rows into column slabs (uneven at world 3), the all-gather of the segment-table row windows, the
+    centroid slabs back to the executor - with the oracle behind the fit; the kernels' bit-identity is tests/test_gpu_kmeans_cols.py and
+    tests/test_gpu_sharded.py.  Same assertions as everywhere in this file: tree, texts, merge centroids, retrieved rows, host RNG streams."""
+    w2 = _run_world(2, dp_lloyd=True)
+    w3 = _run_world(3, dp_lloyd=True)
+    assert w2 == w3 == _run_world(2)
+    assert _run_world(8, dp_lloyd=True) == w2                # 24 one-column segments over 8 ranks: 3 each, the last rank also the empty tail
+    _run_world(3, duplicates=True, dp_lloyd=True)
+
+
 def test_world1_sharded_memory_is_views_and_equal():
     """world size 1: the sharded code path IS the single-stream path (no collective, fetch returns views of the bank)."""
     from streamchat_amd import dist as D, sharded as SH
     import streamchat_amd.utiles as U
     import streamchat_amd.ops as ops
-    saved = (U.weighted_kmeans_feature, ops.sim_topk)
+    saved = (U.weighted_kmeans_feature, ops.sim_topk, ops.kmeans_fit_cols)
     try:
         _patch_providers()
         ref = _single_stream()
@@ -256,7 +297,7 @@ def test_world1_sharded_memory_is_views_and_equal():
         leaf = next(n for n in tree if n.depth == 0)
         assert mem.fetch([leaf.centroids]).data_ptr() == feats[mem.frames_of(leaf.centroids)[0][2]].data_ptr()
     finally:
-        U.weighted_kmeans_feature, ops.sim_topk = saved
+        U.weighted_kmeans_feature, ops.sim_topk, ops.kmeans_fit_cols = saved
 
 
 def test_ref_algebra_and_partition():
