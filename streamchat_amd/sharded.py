@@ -10,6 +10,8 @@ too, from metadata that is identical on every rank:
     of the highest eligible depth (/root/reference/utiles.py:525-536,567-620 via `utiles.plan_merge`) — not one merge per rank;
   * the merge-group k-means runs ONCE, on the rank that owns the group's first row (the rows another rank holds are sent to it
     point to point), with the init rows every rank drew from the same CPU generator: labels / centroids are those of the 1-GPU run.
+    With `dp_lloyd` (SC_DP_LLOYD=1, bench.py --dp-lloyd) it runs DATA-PARALLEL over columns instead (`_dp_lloyd`): every rank clusters the
+    columns of whole SC-KM2 segments and only two small fp64 segment tables are all-gathered per iteration - the same bits at any N.
 
 A tree node's `.centroids` is a `Ref` — a list of (owner rank, store key, row range) — instead of a tensor; tensors stay where they
 were produced until `fetch` moves exactly the selected rows (short-memory frames + retrieved nodes) to the consumer: ONE
