@@ -283,13 +283,19 @@ __global__ __launch_bounds__(64) void km_argmin(const double* __restrict__ seg, 
 }
 
 // single block: stable counting sort of the rows by label (ballot ranks), W[k], empty-cluster ranks
-__global__ __launch_bounds__(1024) void km_order(KmState* __restrict__ st, const float* __restrict__ w, const int* __restrict__ labels32,
-                                                 int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
-                                                 int* __restrict__ empty_rank, int T, int K, int check_done) {
-    if (check_done && st->done) return;
-    extern __shared__ int sm[];               // counts[K] | wave_cnt[16]
-    int* counts = sm;
+// dynamic LDS of km_order: counts[K] | wave_cnt[16] | (weighted fits of up to KM_ORDER_STAGE rows) order[T] | w[T]
+constexpr int KM_ORDER_STAGE = 4096;
+inline size_t km_order_lds(int T, int K) { return sizeof(int) * (size_t)(K + 16) + (T <= KM_ORDER_STAGE ? 8u * (size_t)T : 0u); }
+__device__ __forceinline__ void km_order_body(KmState* __restrict__ st, const float* __restrict__ w, const int* __restrict__ labels32,
+                                              int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
+                                              int* __restrict__ empty_rank, int T, int K, int* sm) {
+    int* counts = sm;                         // counts[K] | wave_cnt[16]
     int* wcnt = sm + K;
+    const bool stage = w && T <= KM_ORDER_STAGE;                 // weighted: the sequential W sums read their rows out of LDS
+    int* ord_s = sm + K + 16;
+    float* w_s = reinterpret_cast<float*>(ord_s + T);
+    if (stage)
+        for (int t = threadIdx.x; t < T; t += blockDim.x) w_s[t] = w[t];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = threadIdx.x; k < K; k += blockDim.x) counts[k] = 0;
     __syncthreads();
@@ -321,18 +327,35 @@ __global__ __launch_bounds__(1024) void km_order(KmState* __restrict__ st, const
             if (lab == k) {
                 int before = 0;
                 for (int i = 0; i < wave; ++i) before += wcnt[i];
-                order[start[k] + counts[k] + before + __popcll(m & ((1ull << lane) - 1ull))] = t;
+                const int pos = start[k] + counts[k] + before + __popcll(m & ((1ull << lane) - 1ull));
+                order[pos] = t;
+                if (stage) ord_s[pos] = t;
             }
             __syncthreads();
             if (threadIdx.x == 0) { int tot = 0; for (int i = 0; i < nw; ++i) tot += wcnt[i]; counts[k] += tot; }
             __syncthreads();
         }
     }
-    // weighted: W[k] = sequential fp32 sum over the cluster's rows in ascending order (SC-KM1)
+    // weighted: W[k] = sequential fp32 sum over the cluster's rows in ascending order (SC-KM1).  The ADDS are sequential; the loads go out eight
+    // at a time and, for fits of up to KM_ORDER_STAGE rows, read LDS copies of `order` and `w` (two dependent GLOBAL round trips per row made
+    // this loop 20 of the 25 us of the launch at T = 400 - and every call of weighted_kmeans_feature is a weighted one: it passes ones)
     if (w) {
+        __syncthreads();                      // `order` / ord_s / w_s were written by other threads of this block
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
             float ws = 0.f;
-            for (int i = start[k]; i < start[k + 1]; ++i) ws = ws + w[order[i]];
+            int i = start[k];
+            const int e = start[k + 1];
+            for (; i + 8 <= e; i += 8) {
+                int o[8];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = stage ? ord_s[i + u] : order[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = stage ? w_s[o[u]] : w[o[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ws = ws + v[u];
+            }
+            for (; i < e; ++i) ws = ws + (stage ? w_s[ord_s[i]] : w[order[i]]);
             W[k] = ws;
         }
         __syncthreads();
@@ -342,6 +365,14 @@ __global__ __launch_bounds__(1024) void km_order(KmState* __restrict__ st, const
             st->n_empty = ne;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void km_order(KmState* __restrict__ st, const float* __restrict__ w, const int* __restrict__ labels32,
+                                                 int* __restrict__ order, int* __restrict__ start, float* __restrict__ W,
+                                                 int* __restrict__ empty_rank, int T, int K, int check_done) {
+    if (check_done && st->done) return;
+    extern __shared__ int sm[];
+    km_order_body(st, w, labels32, order, start, W, empty_rank, T, K, sm);
 }
 
 // one wave per chunk: new centroids + shift partials
@@ -1080,7 +1111,7 @@ int fit_impl(const void* X, int T, int64_t D, int K, const float* wts, const int
         else if (it == 0) km2_launch<2>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
         hipLaunchKernelGGL(km_reduce, rgrid, dim3(256), 0, s, w.gpart, w.st, w.seg, I, ng, 1, (ng + NSEG - 1) / NSEG, 0, NSEG);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, w.seg, w.st, w.labels32, (double*)nullptr, T, K, 1);
-        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
+        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), km_order_lds(T, K), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
         // (the last iteration has no next assign: its update alone is a load-latency-bound pass for km2_pass - 0.49 ms against 0.42 for km_update)
         if (!fused || it + 1 == max_iter) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
         else km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
@@ -1116,7 +1147,7 @@ int fit_cols_impl(const void* X, int T, int64_t D, int K, const float* wts, cons
         SC_CHECK_LAUNCH("sc_kmeans_fit_cols");
         if (exchange(xctx, 0, (sc_stream_t)s) != 0) return sc_fail(SC_ERR_LAUNCH, "sc_kmeans_fit_cols: the exchange of the distance segments failed (iteration %d)", it);
         hipLaunchKernelGGL(km_argmin, dim3((T + 63) / 64), dim3(64), 0, s, seg_dist, w.st, w.labels32, (double*)nullptr, T, K, 1);
-        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
+        hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), km_order_lds(T, K), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 1);
         if (!fused || it + 1 == max_iter) launch_update<Tag>(vec, X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, nch, 0, s);
         else km2_launch<3>(X, w.Ca, w.Cb, w, wts, reseed_idx, n_reseed, T, D, K, s);
         hipLaunchKernelGGL(km_shift_segs, dim3(1), dim3(256), 0, s, w.dgpart, w.st, seg_shift, K, ng, seglen, seg_first, seg_count);
@@ -1157,7 +1188,7 @@ int update_impl(const void* X, int T, int64_t D, int K, const float* wts, const 
                      ((reinterpret_cast<uintptr_t>(C_new) & 15) == 0);
     hipLaunchKernelGGL(km_set_state, dim3(1), dim3(1), 0, s, w.st, 0);
     hipLaunchKernelGGL(km_labels_in, dim3((T + 255) / 256), dim3(256), 0, s, labels, w.labels32, T, K);
-    hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), sizeof(int) * (K + 16), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 0);
+    hipLaunchKernelGGL(km_order, dim3(1), dim3(1024), km_order_lds(T, K), s, w.st, wts, w.labels32, w.order, w.start, w.W, w.empty_rank, T, K, 0);
     float* Ca = const_cast<float*>(C_old);        // state.cur == 0: Ca is read (old centroids), Cb written
     launch_update<Tag>(vec, X, Ca, C_new, w, wts, fill_idx, n_fill, T, D, K, nch, empty_mode, s);
     hipLaunchKernelGGL(km_shift_out, dim3(1), dim3(256), 0, s, w.dgpart, w.W, shift2, wsum, K, ng);

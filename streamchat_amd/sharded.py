@@ -208,7 +208,7 @@ class ShardedMemory:
         windows = [(c[0], c[1]) for c in cols]
         C, _, _, _ = ops.kmeans_fit_cols(X, K, init_idx, reseed_idx, seg_groups, s0, cnt,
                                          lambda what, table: all_gather_row_windows(ctx, table, windows),
-                                         weights=torch.ones(T, dtype=dtype, device=dev), max_iter=self.kmeans_max_iter, tol=1e-4)
+                                         weights=None, max_iter=self.kmeans_max_iter, tol=1e-4)      # (unit weights, as weighted_kmeans_feature passes them on one GPU)
         del X
         mine = C.to(dtype)
         sends, recvs, out, tmp = [], [], None, {}

@@ -119,6 +119,7 @@ def weighted_kmeans_feature(img_feature, video_max_frames, weights=None, *, init
     calls therefore see fresh reseed rows like upstream, but a caller that shares `random` with other code sees a different
     stream position than upstream after a call).  Arithmetic is fp32-canonical (the reference's fp16 distances overflow to inf
     — SURVEY.md §0 item 4)."""
+    unit_weights = weights is None
     if weights is None:
         weights = torch.ones(img_feature.size(0), dtype=img_feature.dtype, device=img_feature.device)
     T, P, D = img_feature.shape
@@ -130,7 +131,9 @@ def weighted_kmeans_feature(img_feature, video_max_frames, weights=None, *, init
         init_idx = torch.randperm(T)[:T0]
     if reseed_idx is None:
         reseed_idx = [random.randint(0, T - 1) for _ in range(max_iter * T0)]
-    C, labels, wsum, info = ops.kmeans_fit(X, T0, init_idx, reseed_idx, weights=weights, max_iter=max_iter, tol=tol)
+    # (the reference's default weights are ones (:292-293): the kernels' unweighted path is the same arithmetic bit for bit - 1 * x = x, sums of ones are
+    #  counts - without a weight load per row and the sequential W sums: tests/test_gpu_kmeans.py::test_unit_weights_equal_no_weights)
+    C, labels, wsum, info = ops.kmeans_fit(X, T0, init_idx, reseed_idx, weights=None if unit_weights else weights, max_iter=max_iter, tol=tol)
     reduced_feature = C.view(T0, P, D).to(img_feature.dtype)
     if return_info:
         return reduced_feature, labels, dict(centroids_f32=C.view(T0, P, D), wsum=wsum, info=info)

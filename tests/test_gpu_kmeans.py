@@ -177,3 +177,24 @@ def test_kmeans_full_size_bit_exact_vs_oracle(T, K, centres_n, max_iter):
     assert int(info[0]) == ref["iters"]
     assert np.array_equal(wsum.cpu().numpy(), ref["wsum"])
     assert np.array_equal(C.cpu().numpy(), ref["centroids"])
+
+
+@pytest.mark.parametrize("T,K,D,dup", [(400, 5, 2048 * 24, False), (64, 8, 2048 * 9 + 64, False), (90, 5, 2048 * 8, True), (200, 3, 2048 * 5, False)])
+def test_unit_weights_equal_no_weights(T, K, D, dup):
+    """`weighted_kmeans_feature` without weights means weights of one (reference utiles.py:292-293).  The kernels' unweighted path must be that
+    arithmetic bit for bit (1 * x = x, a sum of ones is the count, `W > 0` is `count > 0`): centroids, labels, cluster weights, exit iteration
+    and reseed count of `weights=ones` and `weights=None` are identical - which is what lets the host skip the weight vector for the default call."""
+    from streamchat_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    centres = torch.randn(6, D, device="cuda", generator=g)
+    X = (centres[torch.randint(0, 6, (T,), device="cuda", generator=g)] + 0.6 * torch.randn(T, D, device="cuda", generator=g)).half()
+    init = list(range(0, T, T // K))[:K]
+    if dup:
+        X[init[1]] = X[init[0]]
+    rs = [7, 3, 11, 5] * 10
+    a = ops.kmeans_fit(X, K, init, rs, weights=None, max_iter=10, tol=1e-4)
+    b = ops.kmeans_fit(X, K, init, rs, weights=torch.ones(T, device="cuda"), max_iter=10, tol=1e-4)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+    if dup:
+        assert int(a[3][2]) > 0
