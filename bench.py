@@ -848,8 +848,8 @@ def main():
         out["roofline_stages"]["decode"] = dict(bound="hbm", kernel="k_gemv / k_decode_qkv + k_attn_decode (hipGraph)", achieved=round(rate * gb_tok, 1), peak=HBM_PEAK_GBS,
                                                 unit="GB/s", frac=round(rate * gb_tok / HBM_PEAK_GBS, 4), gb_per_token=round(gb_tok, 2))
         try:        # HBM bytes per token from the committed FETCH_SIZE pass over an eager token loop at the same context (rocprofv3's counters do not survive graph replays)
-            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_decode_traffic.json")))
-            out["roofline_stages"]["decode"].update(traffic_gb_per_token=tr["fetched_GB_per_token"], traffic_source="profiles/r05_pmc_decode_traffic.json")
+            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_pmc_decode_traffic.json")))
+            out["roofline_stages"]["decode"].update(traffic_gb_per_token=tr["fetched_GB_per_token"], traffic_source="profiles/r06_pmc_decode_traffic.json")
         except Exception:
             pass
     # (the contract's cpu_baseline before the optional side measurements: whatever happens in them, the line carries it)
