@@ -122,7 +122,7 @@ def test_c5_session_decodes_inside_every_round():
 def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
     """A 1-rank RCCL ("nccl") process group on the GPU box: the sharded step with `always_collective` makes exactly the calls an
     N-rank run makes (all_gather_object of captions, broadcast_object_list of the summary, the int64 Ref broadcast,
-    all_gather_into_tensor of the selected rows) and must still equal the single-GPU step."""
+    all_gather_into_tensor of the selected rows) and must still equal the single-GPU step; then the same with the data-parallel Lloyd."""
     import socket
     import torch.distributed as dist
     import bench
@@ -149,6 +149,20 @@ def test_rccl_single_rank_exercises_every_collective_of_the_sharded_step():
             SH.ShardedMemory.__init__ = orig
         assert torch.equal(b["image_embeddings"], want) and list(b["path_text"]) == list(a["path_text"])
         assert _describe(b["tree"]) == _describe(a["tree"])
+
+        # ... and with the merge k-means DATA-PARALLEL over columns (sharded._dp_lloyd): at one rank the slab is the whole matrix, but the calls
+        # are the N-rank ones - sc_kmeans_fit_cols calling back into Python per Lloyd iteration, the fp64 segment tables through RCCL's
+        # all_gather_into_tensor on the stream the kernels run on - and the merged node's centroids are retrieved rows of this stream
+        def forced_dp(self, *args, **kw):
+            orig(self, *args, always_collective=True, dp_lloyd=True, **kw)
+        SH.ShardedMemory.__init__ = forced_dp
+        try:
+            c = pipe.step_sharded()
+        finally:
+            SH.ShardedMemory.__init__ = orig
+        assert pipe.last["mem"].traffic["dp_lloyd_fits"] >= 1
+        assert torch.equal(c["image_embeddings"], want) and list(c["path_text"]) == list(a["path_text"])
+        assert _describe(c["tree"]) == _describe(a["tree"])
     finally:
         dist.destroy_process_group()
 
