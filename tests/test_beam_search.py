@@ -21,6 +21,9 @@ def test_beam_bookkeeping_reproduces_hf_on_fp32_logits():
     heads, kv, layers, hd = (int(x) for x in d["cfg"])
     cases = json.load(open(os.path.join(G, "qwen2_tiny_beams.json")))["cases"]
     table = sd["model.embed_tokens.weight"]
+    n_all = len(cases)
+    if torch.cuda.is_available():        # on the GPU box (where every test runs under -m gpu) a third of the cases: its host cores take 4x as long for
+        cases = cases[::3]               # this fp32 CPU loop, and all 108 run there on the HIP decoder (test_gpu_beam_search.py) and here in the CPU suite
 
     def logits_of(seq_emb):                                  # last-position logits of one sequence of embeddings
         return R.qwen2_logits(sd, seq_emb, heads=heads, kv_heads=kv, layers=layers, head_dim=hd, last_only=True)
@@ -38,4 +41,4 @@ def test_beam_bookkeeping_reproduces_hf_on_fp32_logits():
         assert toks == c["tokens"], (c["prompt"], N, c["max_new_tokens"], c["eos"], toks, c["tokens"])
         assert abs(score - c["score"]) < 2e-4 * max(1.0, abs(c["score"]))
         n_eos_end += bool(c["eos"]) and toks[-1] in c["eos"]
-    assert len(cases) == 108 and n_eos_end >= 40
+    assert n_all == 108 and n_eos_end >= (40 if len(cases) == n_all else 10)
