@@ -227,40 +227,37 @@ def fast_building_memory_tree_summarize_token(k_means_chunk_feature_list, num_cl
     batch_captions=True: the chunks of this call are captioned by ONE batched generate (BatchDecoder: weights stream
     once per decode step for all chunks) when the summarizer offers `generate_batch_with_image_embedding`; with the reference's
     sampling settings (temperature 0.1) the texts then depend on the batch-wise RNG order, with do_sample=False they are identical."""
-    output_list = []
     if batch_captions and len(chunked_feature_list) > 1 and hasattr(summarizer, "generate_batch_with_image_embedding"):
-        feats = []
-        for chunk_feature in chunked_feature_list:
-            dimension = chunk_feature[0].shape[-1]
-            feats.append([cat_frames(chunk_feature).reshape(-1, dimension).to(summarizer.device)])
-        with torch.no_grad():
-            outs = summarizer.generate_batch_with_image_embedding([input_ids.to(summarizer.device)] * len(feats), feats, modalities=["video"],
-                                                                  do_sample=True, temperature=0.1, max_new_tokens=128)
-        output_list = [tokenizer.batch_decode(o, skip_special_tokens=True)[0].strip() for o in outs]
-        chunked_feature_list = []
-    for chunk_feature in chunked_feature_list:
-        output_list.append(caption_chunk(summarizer, tokenizer, input_ids, chunk_feature))
+        captions = _caption_chunks_batched(summarizer, tokenizer, input_ids, chunked_feature_list)
+    else:
+        captions = [caption_chunk(summarizer, tokenizer, input_ids, frames) for frames in chunked_feature_list]
+    leaves = [MultimodalTreeNode(feature, text, depth=0) for feature, text in zip(k_means_chunk_feature_list, captions)]
+    tree = list(existing_tree) + leaves if existing_tree else leaves
+    first = plan_merge(tree, interval)
+    if first is not None:
+        tree[first:first + interval] = [merge_siblings(tree[first:first + interval], num_clusters, summarizer, tokenizer, conv_templates)]
+    return tree
 
-    nodes = [MultimodalTreeNode(tensor, text, depth=0) for (tensor, text) in zip(k_means_chunk_feature_list, output_list)]
-    if existing_tree:
-        nodes = existing_tree + nodes
 
-    start_index = plan_merge(nodes, interval)
-    if start_index is not None:
-        chunk = nodes[start_index: start_index + interval]
-        centroids_list = [node.centroids for node in chunk]
-        caption_list = [node.text for node in chunk]
-        combined_centroids = cat_frames(centroids_list)
-        if combined_centroids.shape[0] > num_clusters:
-            new_centroids, labels = weighted_kmeans_feature(combined_centroids, num_clusters)
-        else:
-            new_centroids = combined_centroids
-        summarize_text = summarize_captions(summarizer, tokenizer, caption_list, conv_templates)
-        new_node = MultimodalTreeNode(new_centroids, summarize_text, depth=chunk[0].depth + 1)
-        for node in chunk:
-            new_node.children.append(node)
-        nodes[start_index: start_index + interval] = [new_node]
-    return nodes
+def _caption_chunks_batched(summarizer, tokenizer, input_ids, chunked_feature_list):
+    """all chunk captions of one update from ONE batched generate (same prompt, sampling settings and token budget as caption_chunk)"""
+    dev = summarizer.device
+    rows = [[cat_frames(frames).reshape(-1, frames[0].shape[-1]).to(dev)] for frames in chunked_feature_list]
+    with torch.no_grad():
+        outs = summarizer.generate_batch_with_image_embedding([input_ids.to(dev)] * len(rows), rows, modalities=["video"],
+                                                              do_sample=True, temperature=0.1, max_new_tokens=128)
+    return [tokenizer.batch_decode(o, skip_special_tokens=True)[0].strip() for o in outs]
+
+
+def merge_siblings(group, num_clusters, summarizer, tokenizer, conv_templates=None):
+    """`interval` sibling nodes -> their parent (reference utiles.py:581-614): the siblings' frames concatenated and, when there are more than
+    `num_clusters` of them, reduced by the weighted k-means; the parent's text is the LLM's summary of the siblings' texts; one level up."""
+    frames = cat_frames([sib.centroids for sib in group])
+    if frames.shape[0] > num_clusters:
+        frames, _ = weighted_kmeans_feature(frames, num_clusters)
+    parent = MultimodalTreeNode(frames, summarize_captions(summarizer, tokenizer, [sib.text for sib in group], conv_templates), depth=group[0].depth + 1)
+    parent.children.extend(group)
+    return parent
 
 
 def count_nodes_by_depth(nodes):
