@@ -231,11 +231,20 @@ def test_dp_lloyd_processes_retrieve_and_prefill_like_one(nproc):
     assert dp["fits_last_step"] >= 1 and dp["bytes_moved_last_step"] > 400 * 576 * 3584 * 2 * (nproc - 1) // nproc
 
 
+_full_size_one = {}          # tag -> the 1-process record of a full-size job (shared by the tests that compare against it)
+
+
+def _one_process_record(tag, cfg_args):
+    if tag not in _full_size_one:
+        _full_size_one[tag] = _bench_json(cfg_args + ["--force-sharded"], {}, timeout=1100)
+    return _full_size_one[tag]
+
+
 def _full_size_pair(cfg_args, tag):
     """the SAME full-size job as ONE process and as EIGHT processes (bare command: bench.py starts its ranks; all on device 0, gloo with host
     staging); both JSON lines are left under gpurun_out/ when that directory exists (copied to profiles/ by hand)"""
     import json
-    one = _bench_json(cfg_args + ["--force-sharded"], {}, timeout=1100)
+    one = _one_process_record(tag, cfg_args)
     eight = _bench_json(cfg_args + ["--gpus", "8"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=8, launcher="bare", timeout=1100)
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
@@ -258,6 +267,22 @@ def test_c4_full_size_4096_frames_in_8_processes_equals_one_process():
     for k in ("retrieval_crc32", "first_token", "context_tokens"):
         assert one["config"][k] == eight["config"][k], (k, one["config"][k], eight["config"][k])
     assert eight["config"]["frames_rank0"] in (480, 520)
+
+
+@pytest.mark.timeout(1500)
+def test_c4_full_size_in_8_processes_with_the_data_parallel_lloyd_equals_one_process():
+    """The same full-size C4 job with `--dp-lloyd`: the T = 400 x D = 2 064 384 merge k-means runs on EIGHT ranks at once, each on the columns of
+    four SC-KM2 segments (sharded._dp_lloyd -> sc_kmeans_fit_cols; rows transposed into column slabs point to point, the fp64 segment tables
+    all-gathered per Lloyd iteration, centroid slabs to the executor) - and the job still retrieves the same frames and generates the same first
+    token as ONE process, because the fit is bit-identical by construction of the reduction spec."""
+    args = ["--config", "C4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--decode-tokens", "0"]
+    one = _one_process_record("c4_4096", args)
+    eight = _bench_json(args + ["--gpus", "8", "--dp-lloyd"], {"SC_ALL_RANKS_ON_GPU0": "1", "SC_DIST_BACKEND": "gloo"}, nproc=8, launcher="bare", timeout=1100)
+    assert eight["n_gpus"] == 8 and eight["config"]["frames_total"] == 4096
+    for k in ("retrieval_crc32", "first_token", "context_tokens"):
+        assert one["config"][k] == eight["config"][k], (k, one["config"][k], eight["config"][k])
+    dp = eight["collective"]["dp_lloyd"]
+    assert dp["fits_last_step"] == 1 and dp["bytes_moved_last_step"] > 400 * 576 * 3584 * 2 * 7 // 8
 
 
 @pytest.mark.timeout(2400)
